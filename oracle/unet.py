@@ -1,0 +1,327 @@
+"""fp32 CPU restatement of ``Stage2_InapintUNet2DConditionModel`` (oracle; test infrastructure).
+
+Functional: the model is a flat ``dict[str, Tensor]`` keyed by the diffusers state-dict names
+ and ``unet_forward`` walks it in the order of
+/root/reference/src/models/stage2_inpaint_unet_2d_condition.py:579-825.  Block internals follow
+diffusers 0.24.0 (not in the container; restated, see oracle/__init__.py "PARITY UNPINNED").
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class UNetConfig:
+    """Config of the stage-2 UNet.  Defaults = SD-2.1-base ``unet/config.json`` with the kwargs
+    the driver overrides (/root/reference/stage2_batchtest_inpaint_model.py:125-128)."""
+
+    in_channels: int = 9
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    down_block_types: Tuple[str, ...] = (
+        "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D")
+    up_block_types: Tuple[str, ...] = (
+        "UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
+    attention_head_dim: Tuple[int, ...] = (5, 10, 20, 20)  # really head COUNTS (ref :122-128)
+    cross_attention_dim: int = 1024
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    class_embed_type: Optional[str] = "projection"
+    projection_class_embeddings_input_dim: Optional[int] = 1024
+    flip_sin_to_cos: bool = True
+    freq_shift: int = 0
+    use_linear_projection: bool = True
+    sample_size: int = 64
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_out_channels[0] * 4
+
+    @staticmethod
+    def tiny(**kw) -> "UNetConfig":
+        """Small config with the same topology (for fixtures / fast parity)."""
+        base = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4),
+                    cross_attention_dim=64, projection_class_embeddings_input_dim=64,
+                    sample_size=16)
+        base.update(kw)
+        return UNetConfig(**base)
+
+
+# ----------------------------------------------------------------------------- parameter walk
+def _resnet_keys(p: str, cin: int, cout: int, temb: int):
+    yield p + "norm1.weight", (cin,)
+    yield p + "norm1.bias", (cin,)
+    yield p + "conv1.weight", (cout, cin, 3, 3)
+    yield p + "conv1.bias", (cout,)
+    yield p + "time_emb_proj.weight", (cout, temb)
+    yield p + "time_emb_proj.bias", (cout,)
+    yield p + "norm2.weight", (cout,)
+    yield p + "norm2.bias", (cout,)
+    yield p + "conv2.weight", (cout, cout, 3, 3)
+    yield p + "conv2.bias", (cout,)
+    if cin != cout:
+        yield p + "conv_shortcut.weight", (cout, cin, 1, 1)
+        yield p + "conv_shortcut.bias", (cout,)
+
+
+def _transformer_keys(p: str, c: int, ctx: int):
+    yield p + "norm.weight", (c,)
+    yield p + "norm.bias", (c,)
+    yield p + "proj_in.weight", (c, c)
+    yield p + "proj_in.bias", (c,)
+    b = p + "transformer_blocks.0."
+    for i, kdim in ((1, c), (2, ctx)):
+        yield b + f"norm{i}.weight", (c,)
+        yield b + f"norm{i}.bias", (c,)
+        yield b + f"attn{i}.to_q.weight", (c, c)
+        yield b + f"attn{i}.to_k.weight", (c, kdim)
+        yield b + f"attn{i}.to_v.weight", (c, kdim)
+        yield b + f"attn{i}.to_out.0.weight", (c, c)
+        yield b + f"attn{i}.to_out.0.bias", (c,)
+    yield b + "norm3.weight", (c,)
+    yield b + "norm3.bias", (c,)
+    yield b + "ff.net.0.proj.weight", (8 * c, c)
+    yield b + "ff.net.0.proj.bias", (8 * c,)
+    yield b + "ff.net.2.weight", (c, 4 * c)
+    yield b + "ff.net.2.bias", (c,)
+    yield p + "proj_out.weight", (c, c)
+    yield p + "proj_out.bias", (c,)
+
+
+def param_shapes(cfg: UNetConfig) -> Iterator[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) for every tensor of the state dict."""
+    boc = cfg.block_out_channels
+    temb = cfg.time_embed_dim
+    ctx = cfg.cross_attention_dim
+    L = cfg.layers_per_block
+    yield "conv_in.weight", (boc[0], cfg.in_channels, 3, 3)
+    yield "conv_in.bias", (boc[0],)
+    yield "time_embedding.linear_1.weight", (temb, boc[0])
+    yield "time_embedding.linear_1.bias", (temb,)
+    yield "time_embedding.linear_2.weight", (temb, temb)
+    yield "time_embedding.linear_2.bias", (temb,)
+    if cfg.class_embed_type == "projection":
+        d = cfg.projection_class_embeddings_input_dim
+        yield "class_embedding.linear_1.weight", (temb, d)
+        yield "class_embedding.linear_1.bias", (temb,)
+        yield "class_embedding.linear_2.weight", (temb, temb)
+        yield "class_embedding.linear_2.bias", (temb,)
+    out = boc[0]
+    for i, typ in enumerate(cfg.down_block_types):
+        cin, out = out, boc[i]
+        for j in range(L):
+            if typ == "CrossAttnDownBlock2D":
+                yield from _transformer_keys(f"down_blocks.{i}.attentions.{j}.", out, ctx)
+        for j in range(L):
+            yield from _resnet_keys(f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else out, out, temb)
+        if i != len(boc) - 1:
+            yield f"down_blocks.{i}.downsamplers.0.conv.weight", (out, out, 3, 3)
+            yield f"down_blocks.{i}.downsamplers.0.conv.bias", (out,)
+    rev = list(reversed(boc))
+    out = rev[0]
+    for i, typ in enumerate(cfg.up_block_types):
+        prev, out = out, rev[i]
+        inc = rev[min(i + 1, len(boc) - 1)]
+        for j in range(L + 1):
+            if typ == "CrossAttnUpBlock2D":
+                yield from _transformer_keys(f"up_blocks.{i}.attentions.{j}.", out, ctx)
+        for j in range(L + 1):
+            skip = inc if j == L else out
+            rin = prev if j == 0 else out
+            yield from _resnet_keys(f"up_blocks.{i}.resnets.{j}.", rin + skip, out, temb)
+        if i != len(boc) - 1:
+            yield f"up_blocks.{i}.upsamplers.0.conv.weight", (out, out, 3, 3)
+            yield f"up_blocks.{i}.upsamplers.0.conv.bias", (out,)
+    c = boc[-1]
+    yield from _transformer_keys("mid_block.attentions.0.", c, ctx)
+    yield from _resnet_keys("mid_block.resnets.0.", c, c, temb)
+    yield from _resnet_keys("mid_block.resnets.1.", c, c, temb)
+    yield "conv_norm_out.weight", (boc[0],)
+    yield "conv_norm_out.bias", (boc[0],)
+    yield "conv_out.weight", (cfg.out_channels, boc[0], 3, 3)
+    yield "conv_out.bias", (cfg.out_channels,)
+
+
+def param_count(cfg: UNetConfig) -> int:
+    return sum(math.prod(s) for _, s in param_shapes(cfg))
+
+
+_HALF_SCALED = ("conv_out.weight", ".conv2.weight", ".to_out.0.weight", ".ff.net.2.weight",
+                ".proj_out.weight")
+
+
+def synth_state_dict(cfg: UNetConfig, seed: int = 0, random_affine: bool = False,
+                     dtype=torch.float32) -> Dict[str, Tensor]:
+    """Seeded synthetic weights: Linear/Conv ~ U(+-1/sqrt(fan_in)), norm gamma=1
+    beta=0 (or random affine), a few output projections scaled by 0.5.  Each tensor has its own
+    CPU generator seeded from (seed, crc32(key)) so the result does not depend on key order."""
+    shapes = dict(param_shapes(cfg))
+    sd: Dict[str, Tensor] = {}
+    for key, shape in shapes.items():
+        g = torch.Generator(device="cpu")
+        g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+        is_weight = key.endswith("weight")
+        if len(shapes[key[: key.rfind(".") + 1] + "weight"]) == 1:  # GroupNorm / LayerNorm affine
+            if random_affine:
+                t = torch.rand(shape, generator=g) * 0.5 + 0.75 if is_weight \
+                    else (torch.rand(shape, generator=g) - 0.5) * 0.4
+            else:
+                t = torch.ones(shape) if is_weight else torch.zeros(shape)
+        else:
+            fan_in = math.prod(shapes[key[: key.rfind(".") + 1] + "weight"][1:])
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            if is_weight and any(key.endswith(s) for s in _HALF_SCALED):
+                t = t * 0.5
+        sd[key] = t.to(dtype)
+    return sd
+
+
+# ----------------------------------------------------------------------------- blocks [D-0.24]
+def timestep_embedding(t: Tensor, dim: int, flip_sin_to_cos: bool = True, shift: float = 0.0) -> Tensor:
+    """Appendix A-1 (diffusers ``Timesteps``; built at ref :184)."""
+    half = dim // 2
+    k = torch.arange(half, dtype=torch.float32)
+    f = torch.exp(-math.log(10000.0) * k / (half - shift))
+    a = t.float()[:, None] * f[None, :]
+    s, c = torch.sin(a), torch.cos(a)
+    return torch.cat([c, s], -1) if flip_sin_to_cos else torch.cat([s, c], -1)
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + "weight"], sd.get(p + "bias"))
+
+
+def timestep_mlp(sd, p, x):
+    """Appendix A-2 ``TimestepEmbedding``: linear_2(silu(linear_1(x)))."""
+    return _lin(sd, p + "linear_2.", F.silu(_lin(sd, p + "linear_1.", x)))
+
+
+def resnet_block(sd, p, x, emb, groups, eps):
+    """Appendix A-3 ``ResnetBlock2D`` (time_embedding_norm 'default', output_scale_factor 1)."""
+    h = F.group_norm(x, groups, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    h = F.conv2d(F.silu(h), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    h = h + _lin(sd, p + "time_emb_proj.", F.silu(emb))[:, :, None, None]
+    h = F.group_norm(h, groups, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+    h = F.conv2d(F.silu(h), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    if p + "conv_shortcut.weight" in sd:
+        x = F.conv2d(x, sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"])
+    return x + h
+
+
+def attention(sd, p, x, ctx, heads):
+    """Appendix A-7 ``Attention`` (no mask; scale = head_dim**-0.5)."""
+    B, N, C = x.shape
+    c = x if ctx is None else ctx
+    q = F.linear(x, sd[p + "to_q.weight"])
+    k = F.linear(c, sd[p + "to_k.weight"])
+    v = F.linear(c, sd[p + "to_v.weight"])
+    d = C // heads
+    q = q.view(B, N, heads, d).transpose(1, 2)
+    k = k.view(B, -1, heads, d).transpose(1, 2)
+    v = v.view(B, -1, heads, d).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
+    o = torch.softmax(s, dim=-1) @ v
+    o = o.transpose(1, 2).reshape(B, N, C)
+    return _lin(sd, p + "to_out.0.", o)
+
+
+def basic_transformer_block(sd, p, x, ctx, heads):
+    """Appendix A-6/A-8 ``BasicTransformerBlock`` with GEGLU feed-forward."""
+    C = x.shape[-1]
+    x = x + attention(sd, p + "attn1.", F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5), None, heads)
+    x = x + attention(sd, p + "attn2.", F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5), ctx, heads)
+    h = F.layer_norm(x, (C,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
+    pr = _lin(sd, p + "ff.net.0.proj.", h)
+    a, g = pr.chunk(2, dim=-1)
+    return x + _lin(sd, p + "ff.net.2.", a * F.gelu(g))
+
+
+def transformer_2d(sd, p, x, ctx, heads, groups):
+    """Appendix A-5 ``Transformer2DModel`` (use_linear_projection=True, 1 layer, GN eps 1e-6)."""
+    B, C, H, W = x.shape
+    r = x
+    h = F.group_norm(x, groups, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    h = _lin(sd, p + "proj_in.", h)
+    h = basic_transformer_block(sd, p + "transformer_blocks.0.", h, ctx, heads)
+    h = _lin(sd, p + "proj_out.", h)
+    return h.reshape(B, H, W, C).permute(0, 3, 1, 2) + r
+
+
+def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timestep, encoder_hidden_states: Tensor,
+                 class_labels: Optional[Tensor] = None, my_pose_cond: Optional[Tensor] = None,
+                 taps: Optional[dict] = None) -> Tensor:
+    """Forward of the stage-2 UNet; order follows ref stage2_inpaint_unet_2d_condition.py:661-820.
+
+    ``taps`` (optional dict) receives named intermediate activations for per-layer parity."""
+    G, eps = cfg.norm_num_groups, cfg.norm_eps
+    boc = cfg.block_out_channels
+    heads = cfg.attention_head_dim
+    L = cfg.layers_per_block
+    B = sample.shape[0]
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    # 1. time (ref :661-684)
+    t = timestep
+    if not torch.is_tensor(t):
+        t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64)
+    elif t.dim() == 0:
+        t = t[None]
+    t = t.expand(B)
+    t_emb = timestep_embedding(t, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift).to(sample.dtype)
+    emb = timestep_mlp(sd, "time_embedding.", t_emb)
+    # class embedding (ref :687-708)
+    if cfg.class_embed_type == "projection":
+        if class_labels is None:
+            raise ValueError("class_labels should be provided when num_class_embeds > 0")
+        emb = emb + timestep_mlp(sd, "class_embedding.", class_labels.squeeze(1))
+    tap("emb", emb)
+    # 2. pre-process (ref :742) -- the one PCDMs-specific op
+    x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1) + my_pose_cond
+    tap("conv_in", x)
+    # 3. down (ref :746-761)
+    skips: List[Tensor] = [x]
+    for i, typ in enumerate(cfg.down_block_types):
+        for j in range(L):
+            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}.", x, emb, G, eps)
+            if typ == "CrossAttnDownBlock2D":
+                x = transformer_2d(sd, f"down_blocks.{i}.attentions.{j}.", x, encoder_hidden_states, heads[i], G)
+            tap(f"down{i}.{j}", x)
+            skips.append(x)
+        if i != len(boc) - 1:
+            x = F.conv2d(x, sd[f"down_blocks.{i}.downsamplers.0.conv.weight"],
+                         sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], stride=2, padding=1)
+            skips.append(x)
+    # 4. mid (ref :775-783)
+    x = resnet_block(sd, "mid_block.resnets.0.", x, emb, G, eps)
+    x = transformer_2d(sd, "mid_block.attentions.0.", x, encoder_hidden_states, heads[-1], G)
+    x = resnet_block(sd, "mid_block.resnets.1.", x, emb, G, eps)
+    tap("mid", x)
+    # 5. up (ref :789-814)
+    rheads = list(reversed(heads))
+    for i, typ in enumerate(cfg.up_block_types):
+        for j in range(L + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}.", x, emb, G, eps)
+            if typ == "CrossAttnUpBlock2D":
+                x = transformer_2d(sd, f"up_blocks.{i}.attentions.{j}.", x, encoder_hidden_states, rheads[i], G)
+            tap(f"up{i}.{j}", x)
+        if i != len(boc) - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = F.conv2d(x, sd[f"up_blocks.{i}.upsamplers.0.conv.weight"],
+                         sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
+    # 6. post-process (ref :817-820)
+    x = F.silu(F.group_norm(x, G, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps))
+    return F.conv2d(x, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
