@@ -1,0 +1,124 @@
+/* pcdm.h -- C-ABI of libpcdm.so: the MI355X (gfx950) kernels behind the PCDMs stage-2 denoise loop.
+ *
+ * The reference (tencent-ailab/PCDMs) has NO native/FFI boundary for this path: its boundary is
+ * two Python objects, pipe.unet and pipe.scheduler (stage2_batchtest_inpaint_model.py:125-132),
+ * and every device op is an ATen/cuDNN/cuBLAS/xformers call made from inside diffusers 0.24.0.
+ * Each entry point below therefore cites the reference / diffusers op it replaces (SURVEY.md §2.1
+ * K-numbers); the Python mirror of the reference interface lives in pcdms_amd/ and calls these
+ * through ctypes.
+ *
+ * Conventions: plain pointers to DEVICE memory, sizes as ints, a hipStream_t (passed as void*),
+ * every call asynchronous on that stream, no allocation inside, no global state.  Activations
+ * are NHWC / token-major bf16 ("u16" storage); statistics, biases and time embeddings fp32.
+ * Return 0 on success, a negative code on bad arguments (-1) or launch failure (<= -1000).
+ */
+#ifndef PCDM_H
+#define PCDM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pcdm_stream_t; /* hipStream_t */
+
+int pcdm_version(void);
+/* 1 only for the test-only CPU lane emulator build (tests/emu); the product .so returns 0. */
+int pcdm_is_emulator(void);
+
+/* ---- K4 GroupNorm(+SiLU)  [torch.nn.GroupNorm inside ResnetBlock2D.norm1/2, Transformer2DModel.norm,
+ *      conv_norm_out: stage2_inpaint_unet_2d_condition.py:435-441,817-819].
+ * x = virtual channel-concat of x1 [B,HW,C1] and x2 [B,HW,C2] (x2 may be NULL, C2 = 0): the up-block
+ * skip concat (ref :792-793, K6) is never materialised.  y [B,HW,C1+C2] bf16.
+ * ws: fp32 workspace of pcdm_groupnorm_ws_floats(B, C1+C2) floats. */
+int64_t pcdm_groupnorm_ws_floats(int B, int C);
+int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
+                   const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
+
+/* ---- K8 LayerNorm  [BasicTransformerBlock.norm1/2/3, diffusers attention.py]  x,y [rows,C] bf16 */
+int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma, const float* beta,
+                   pcdm_stream_t s);
+
+/* ---- K1/K2/K3/K5/K6/K7/K11 GEMM / implicit-GEMM conv3x3 on MFMA with fused epilogues.
+ *  out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
+ *  A (bf16), one of
+ *    linear : A[m, k] = (k < c1 ? a[m*lda + k] : a2[m*lda2 + k - c1])      (Linear, 1x1 conv, skip concat)
+ *    conv3x3: m = (b, oy, ox) over [B, Ho, Wo]; k = (ky*3+kx)*cin + c; pad 1; stride 1|2;
+ *             upsample=1 reads a[b, iy>>1, ix>>1, c] (nearest x2 folded in: Upsample2D, K5)
+ *  W: packed bf16 [Npad, K] (K contiguous; rows >= N zero).  K % 64 == 0, Npad % 64 == 0.
+ *  epilogue: + bias[n] + rowvec[m / rows_per_batch, n] + residual[(m % res_mod), n]  then
+ *    PCDM_EPI_STORE   : out[m*ldo + n]                                bf16
+ *    PCDM_EPI_GEGLU   : W rows interleaved per 64 as [32 h | 32 gate]; out[m*ldo + n/2..] = h*gelu(gate)
+ *    PCDM_EPI_SPLIT_VT: n <  vt_col0 -> out[m*ldo + n];  n >= vt_col0 -> out2[b, n - vt_col0, t]
+ *                       with m = b*rows_per_batch + t, out2 pitch ldo2 (V^T for pcdm_flash_attn)
+ *    PCDM_EPI_NCHW_F32: out as fp32 [B, N, rows_per_batch] (conv_out -> eps in NCHW) */
+enum { PCDM_EPI_STORE = 0, PCDM_EPI_GEGLU = 1, PCDM_EPI_SPLIT_VT = 2, PCDM_EPI_NCHW_F32 = 3 };
+typedef struct pcdm_gemm_params {
+    const void* a;
+    const void* a2;
+    int64_t lda, lda2;
+    int32_t c1;
+    int32_t conv;      /* 0 linear, 1 conv3x3 */
+    int32_t B, Hi, Wi, Ho, Wo, stride, upsample, cin;
+    const void* w;
+    int32_t M, N, K, Npad;
+    const float* bias;
+    const float* rowvec;
+    int32_t rows_per_batch;
+    const void* residual;
+    int64_t ldr;
+    int32_t res_mod;
+    int32_t epilogue;
+    int32_t vt_col0;
+    void* out;
+    int64_t ldo;
+    void* out2;
+    int64_t ldo2;
+    int32_t tile;      /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64 */
+} pcdm_gemm_params;
+int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
+
+/* ---- K9/K10 fused attention (replaces xformers.ops.memory_efficient_attention enabled at
+ *      stage2_batchtest_inpaint_model.py:133).  head_dim = 64.  softmax(q k^T * scale) v, fp32 softmax.
+ *  q  [B*Lq, ldq]  bf16, head h at columns [64h, 64h+64)
+ *  k  [B*Lk, ldk]  bf16, same head layout
+ *  vt [B, H*64, ldvt] bf16 = V transposed (key index contiguous), as written by PCDM_EPI_SPLIT_VT
+ *  o  [B*Lq, ldo]  bf16 */
+int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                    void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, pcdm_stream_t s);
+
+/* ---- K12 time / class embedding helpers.
+ * pcdm_timestep_embedding: diffusers Timesteps(dim, flip_sin_to_cos, shift) (ref :184,677): out fp32 [B,dim];
+ *   t read from DEVICE memory: t_dev[step_dev ? *step_dev : 0] (int64), broadcast over B.
+ * pcdm_small_linear: y[b,n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), x,y fp32, W bf16 [N,K],
+ *   B <= 32; act flags: 1 = SiLU.  (TimestepEmbedding MLPs ref :191-197,247; every ResnetBlock2D.time_emb_proj) */
+int pcdm_timestep_embedding(const int64_t* t_dev, const int32_t* step_dev, float* out, int B, int dim,
+                            int flip_sin_to_cos, float shift, pcdm_stream_t s);
+int pcdm_small_linear(const float* x, const void* w, const float* bias, const float* add, float* y, int B, int K,
+                      int N, int act_in, int act_out, pcdm_stream_t s);
+
+/* ---- P-2 input assembly: cat([cat([latents]*2), mask, masked_latents], 1) (stage2_inpaint_pipeline.py:499-501)
+ * -> NHWC bf16 [Bout, h, w, cpad] with channels >= 9 zero.  latents fp32 NCHW [N,4,h,w]; Bout = rep*N rows
+ * (rep = 2 with CFG); mask fp32 [1|Bout,1,h,w]; masked fp32 [1|Bout,4,h,w] (batch-broadcast when *_b == 1). */
+int pcdm_assemble_input(const float* latents, int N, int rep, const float* mask, int mask_b, const float* masked,
+                        int masked_b, void* out, int h, int w, int cpad, pcdm_stream_t s);
+/* NCHW fp32 -> NHWC bf16 (pose feature st_pose_f, ref :430-431) and back. */
+int pcdm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, pcdm_stream_t s);
+int pcdm_nhwc_bf16_to_nchw_f32(const void* x, float* y, int B, int C, int HW, pcdm_stream_t s);
+int pcdm_f32_to_bf16(const float* x, void* y, int64_t n, pcdm_stream_t s);
+
+/* ---- K13 CFG combine + scheduler step (stage2_inpaint_pipeline.py:510-519).
+ * eps [2N or N, C*HW] fp32 (uncond rows first).  g = guidance scale (cfg=0: eps used as is).
+ * x_prev = cx*x + ce*eps_guided (+ cn*noise); coefficients read from DEVICE table coef[step][4] =
+ * {cx, ce, cn, unused} at index *step_dev so that one captured hipGraph serves every step.
+ * Optionally writes the guided eps (eps_out) and x0 = c0x*x + c0e*eps is left to the host scheduler. */
+int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x, const float* noise, float* x_prev,
+                  float* eps_out, const float* coef, const int32_t* step_dev, int64_t n, pcdm_stream_t s);
+/* y = sum_i c[i] * x_i  (i < nin <= 6), fp32; UniPC predictor/corrector linear combinations. */
+int pcdm_lincomb(float* y, int nin, const float* const* xs, const float* c, int64_t n, pcdm_stream_t s);
+/* *step_dev += 1 */
+int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

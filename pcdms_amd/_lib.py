@@ -1,0 +1,93 @@
+"""ctypes binding of libpcdm.so (include/pcdm.h).
+
+The product path has exactly one implementation of every op: the hipcc-built gfx950 library.  If
+it is missing this module raises -- there is no eager / CPU fallback.  (``use_library`` exists so
+tests can inject the lane-emulator build of the *same sources*; the product never calls it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libpcdm.so"
+
+_lib: Optional[C.CDLL] = None
+_is_emu = False
+
+
+class GemmParams(C.Structure):
+    """Mirror of ``pcdm_gemm_params`` (include/pcdm.h)."""
+
+    _fields_ = [
+        ("a", C.c_void_p), ("a2", C.c_void_p), ("lda", C.c_int64), ("lda2", C.c_int64),
+        ("c1", C.c_int32), ("conv", C.c_int32),
+        ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32), ("cin", C.c_int32),
+        ("w", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("Npad", C.c_int32),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rows_per_batch", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int64), ("res_mod", C.c_int32),
+        ("epilogue", C.c_int32), ("vt_col0", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out2", C.c_void_p), ("ldo2", C.c_int64),
+        ("tile", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "pcdm_version": ([], C.c_int),
+    "pcdm_is_emulator": ([], C.c_int),
+    "pcdm_groupnorm_ws_floats": ([_I, _I], _L),
+    "pcdm_groupnorm": ([_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
+    "pcdm_layernorm": ([_P, _P, _I, _I, _F, _P, _P, _P], C.c_int),
+    "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),
+    "pcdm_flash_attn": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
+    "pcdm_timestep_embedding": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
+    "pcdm_small_linear": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "pcdm_assemble_input": ([_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P], C.c_int),
+    "pcdm_nchw_f32_to_nhwc_bf16": ([_P, _P, _I, _I, _I, _P], C.c_int),
+    "pcdm_nhwc_bf16_to_nchw_f32": ([_P, _P, _I, _I, _I, _P], C.c_int),
+    "pcdm_f32_to_bf16": ([_P, _P, _L, _P], C.c_int),
+    "pcdm_cfg_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
+    "pcdm_lincomb": ([_P, _I, C.POINTER(_P), C.POINTER(_F), _L, _P], C.c_int),
+    "pcdm_advance_step": ([_P, _P], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.argtypes = args
+        fn.restype = res
+    return lib
+
+
+def use_library(lib: C.CDLL) -> None:
+    """Install an already-loaded library (tests: the emulator build of the same sources)."""
+    global _lib, _is_emu
+    _lib = _bind(lib)
+    _is_emu = bool(lib.pcdm_is_emulator())
+
+
+def load(path: Optional[Path] = None) -> C.CDLL:
+    global _lib, _is_emu
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} not found: the HIP kernel library is not built.  Run `python -m pcdms_amd.build` "
+            "(needs hipcc); pcdms_amd has no fallback implementation.")
+    _lib = _bind(C.CDLL(str(p)))
+    _is_emu = bool(_lib.pcdm_is_emulator())
+    return _lib
+
+
+def lib() -> C.CDLL:
+    return _lib if _lib is not None else load()
+
+
+def is_emulator() -> bool:
+    lib()
+    return _is_emu

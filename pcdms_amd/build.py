@@ -1,0 +1,61 @@
+"""Build libpcdm.so (hand-written HIP kernels for gfx950) in-tree with hipcc.
+
+``python -m pcdms_amd.build`` or ``pcdms_amd.build.build_lib()``.  hipcc cross-compiles for
+gfx950 without a GPU; the resulting ``pcdms_amd/lib/libpcdm.so`` is git-ignored but travels to the
+GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "lib"
+LIB = LIBDIR / "libpcdm.so"
+SOURCES = ["norm.hip", "gemm.hip", "attn.hip", "misc.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libpcdm.so)")
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    LIBDIR.mkdir(exist_ok=True)
+    headers = [CSRC / "pcdm_device.h", ROOT.parent / "include" / "pcdm.h"]
+    objs = []
+    for src in SOURCES:
+        s = CSRC / src
+        o = LIBDIR / (src + ".o")
+        if force or _stale(o, [s, *headers]):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+                   "-Wno-unused-result", "-c", str(s), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(str(o))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,173 @@
+// Fused (flash-style) attention for head_dim 64 on gfx950 (SURVEY.md §2.1 K9 self-attention,
+// K10 cross-attention).  Replaces xformers.ops.memory_efficient_attention
+// (stage2_batchtest_inpaint_model.py:133): o = softmax(q k^T * scale) v, fp32 softmax, no mask.
+//
+// Design (wave = 64, v_mfma_f32_32x32x16_bf16):
+//  * workgroup = 4 waves; each wave owns 32 query rows and the whole head_dim; K / V^T tiles of
+//    64 keys are register-staged into double-buffered LDS by all 256 threads (one barrier per tile).
+//  * QK^T is issued "swapped": S^T = K * Q^T, so a lane holds 32 scores of ONE query (the other 32
+//    live in lane^32).  Row max / row sum are 31 in-register ops + one __shfl_xor(.,32); the online
+//    softmax rescale of O^T is lane-uniform.  No serial-lane softmax, no LDS round trip for P.
+//  * The K rows fed to MFMA row i are keys pi(i) (bits 2 and 3 of i swapped).  With that
+//    permutation the 8 accumulator registers r = 8s..8s+7 of a lane are exactly the 8 consecutive
+//    keys the lane must supply as the B operand of O^T += V^T * P^T, so P goes from accumulator to
+//    MFMA operand with a bf16 convert only (no permlane / ds_bpermute).
+//  * V is consumed as V^T [d][key] (key contiguous): the projection GEMM writes it transposed
+//    (PCDM_EPI_SPLIT_VT), so the A operand of the PV MFMA is a plain ds_read_b128 -- no transpose
+//    anywhere in this kernel.
+//  * LDS rows padded 64 -> 72 bf16 (conflict-free ds_read_b128 / ds_write_b128, see gemm.hip).
+#include "pcdm_device.h"
+#include "../../include/pcdm.h"
+
+namespace {
+constexpr int KB = 64;     // keys per tile
+constexpr int LDSK = 72;   // padded LDS row (bf16)
+constexpr int QPW = 32;    // queries per wave
+constexpr int QPB = 128;   // queries per workgroup
+
+__global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
+                                                         const u16* __restrict__ k, int64_t ldk,
+                                                         const u16* __restrict__ vt, int64_t ldvt,
+                                                         u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
+                                                         float c /* scale * log2(e) */) {
+    __shared__ __attribute__((aligned(16))) u16 Ks[2][KB][LDSK];
+    __shared__ __attribute__((aligned(16))) u16 Vs[2][64][LDSK];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QPB + wave * QPW;
+    const int hh = lane >> 5, col = lane & 31;
+
+    // Q fragments (B operand of S^T = K Q^T): lane -> query col, d = 16*ks + 8*hh + e
+    int qrow = q0 + col;
+    const bool qvalid = qrow < Lq;
+    if (!qvalid) qrow = Lq - 1;
+    const u16* qp = q + ((int64_t)b * Lq + qrow) * ldq + h * 64 + hh * 8;
+    u16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u16x8*)(qp + ks * 16);
+
+    // staging coordinates: 2 chunks of K and 2 chunks of V^T per thread
+    const int cc = t & 7, rr = t >> 3;
+    const u16* kbase = k + (int64_t)b * Lk * ldk + h * 64 + cc * 8;
+    const u16* vbase = vt + ((int64_t)(b * H + h) * 64) * ldvt + cc * 8;
+    u16x8 rk[2], rv[2];
+    auto load_tile = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = key0 + rr + 32 * i;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (key < Lk) v = *(const u16x8*)(kbase + (int64_t)key * ldk);
+            rk[i] = v;
+            u16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (key0 + cc * 8 < ldvt) w = *(const u16x8*)(vbase + (int64_t)(rr + 32 * i) * ldvt + key0);
+            rv[i] = w;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(u16x8*)&Ks[buf][rr + 32 * i][cc * 8] = rk[i];
+            *(u16x8*)&Vs[buf][rr + 32 * i][cc * 8] = rv[i];
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);  // K row permutation
+    const int nkb = (Lk + KB - 1) / KB;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = kb & 1, key0 = kb * KB;
+        if (kb + 1 < nkb) load_tile(key0 + KB);
+
+        // ---- S^T = K Q^T  (two 32-key fragments)
+        f32x16 s[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) {
+                const u16x8 kfrag = *(const u16x8*)&Ks[cur][kf * 32 + pi][ks * 16 + hh * 8];
+                s[kf] = mfma_32x32x16(kfrag, qf[ks], s[kf]);
+            }
+        }
+        // lane holds: s[kf][r] = score(query col, key key0 + 32kf + 16(r>>3) + 8hh + (r&7))
+        if (key0 + KB > Lk) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + 32 * kf + 16 * (r >> 3) + 8 * hh + (r & 7) >= Lk) s[kf][r] = -1e30f;
+        }
+        // ---- online softmax (fp32)
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float lsum = 0.f;
+        u16x8 pf[4];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(fmaf(s[kf][r], c, -mc));
+                lsum += pv;
+                pf[2 * kf + (r >> 3)][r & 7] = f2bf(pv);
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oacc[0][r] *= alpha;
+            oacc[1][r] *= alpha;
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                const u16x8 vfrag = *(const u16x8*)&Vs[cur][df * 32 + col][s4 * 16 + hh * 8];
+                oacc[df] = mfma_32x32x16(vfrag, pf[s4], oacc[df]);
+            }
+        }
+        if (kb + 1 < nkb) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qvalid) {
+        u16* op = o + ((int64_t)b * Lq + qrow) * ldo + h * 64;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                u16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = f2bf(oacc[df][4 * rg + e] * inv);
+                *(u16x4*)(op + df * 32 + 8 * rg + 4 * hh) = ov;
+            }
+    }
+}
+}  // namespace
+
+extern "C" int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                               void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, pcdm_stream_t s) {
+    if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
+    if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < Lk) return -1;
+    const dim3 grid((Lq + QPB - 1) / QPB, H, B);
+    PCDM_LAUNCH(flash_attn_kernel, grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
+                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}

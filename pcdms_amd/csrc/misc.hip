@@ -1,0 +1,246 @@
+// Small / elementwise kernels of the stage-2 denoise step (SURVEY.md §2.1 K12, K13 and the
+// input assembly of stage2_inpaint_pipeline.py:499-501).  All HBM- or latency-bound; 16-byte
+// vector accesses where the layout allows, device-resident step index so one captured hipGraph
+// replays for every timestep.
+#include "pcdm_device.h"
+#include "../../include/pcdm.h"
+
+namespace {
+// out[b, j]: diffusers Timesteps (flip_sin_to_cos => [cos | sin])
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t_dev, const int32_t* __restrict__ step_dev,
+                                          float* __restrict__ out, int B, int dim, int flip, float shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int j = i % dim, half = dim / 2;
+    const float tv = (float)t_dev[step_dev ? *step_dev : 0];
+    const int kk = j < half ? j : j - half;
+    const float f = expf(-9.210340371976184f * (float)kk / ((float)half - shift));
+    const float a = tv * f;
+    const bool is_cos = flip ? (j < half) : (j >= half);
+    out[i] = is_cos ? cosf(a) : sinf(a);
+}
+
+// y[b, n] = act_out( sum_k act_in(x[b,k]) W[n,k] + bias[n] ) + add[b,n]; one wave per n.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const u16* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ add, float* __restrict__ y,
+                                                           int B, int K, int N, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool valid = n < N;
+    const u16* wr = w + (int64_t)(valid ? n : 0) * K;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const u16x8 wv = *(const u16x8*)(wr + k);
+            float wf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[e] = bf2f(wv[e]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (b0 + i < B) {
+                    const float* xr = x + (int64_t)(b0 + i) * K + k;
+                    const f32x4 x0 = *(const f32x4*)xr, x1 = *(const f32x4*)(xr + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a0 = x0[e], a1 = x1[e];
+                        if (act_in) {
+                            a0 = silu_f(a0);
+                            a1 = silu_f(a1);
+                        }
+                        acc[i] += a0 * wf[e] + a1 * wf[e + 4];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0 && valid && b0 + i < B) {
+                float v = s + (bias ? bias[n] : 0.f);
+                if (act_out) v = silu_f(v);
+                if (add) v += add[(int64_t)(b0 + i) * N + n];
+                y[(int64_t)(b0 + i) * N + n] = v;
+            }
+        }
+    }
+}
+
+__global__ void assemble_input_kernel(const float* __restrict__ latents, int N, int rep,
+                                      const float* __restrict__ mask, int mask_b, const float* __restrict__ masked,
+                                      int masked_b, u16* __restrict__ out, int HW, int cpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, pixel, octet)
+    const int noct = cpad / 8;
+    const int64_t total = (int64_t)N * rep * HW * noct;
+    if (i >= total) return;
+    const int oc = (int)(i % noct);
+    const int64_t bp = i / noct;
+    const int pix = (int)(bp % HW), b = (int)(bp / HW);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = oc * 8 + e;
+        float v = 0.f;
+        if (c < 4) v = latents[((int64_t)(b % N) * 4 + c) * HW + pix];
+        else if (c == 4) v = mask[(int64_t)(mask_b == 1 ? 0 : b) * HW + pix];
+        else if (c < 9) v = masked[((int64_t)(masked_b == 1 ? 0 : b) * 4 + (c - 5)) * HW + pix];
+        o[e] = f2bf(v);
+    }
+    *(u16x8*)(out + i * 8) = o;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, u16* __restrict__ y, int C, int HW, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, pixel, octet)
+    if (i >= total) return;
+    const int noct = C / 8;
+    const int oc = (int)(i % noct);
+    const int64_t bp = i / noct;
+    const int pix = (int)(bp % HW);
+    const int64_t b = bp / HW;
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(x[(b * C + oc * 8 + e) * HW + pix]);
+    *(u16x8*)(y + i * 8) = o;
+}
+
+__global__ void nhwc_to_nchw_kernel(const u16* __restrict__ x, float* __restrict__ y, int C, int HW, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, c, pix)
+    if (i >= total) return;
+    const int pix = (int)(i % HW);
+    const int64_t bc = i / HW;
+    const int c = (int)(bc % C);
+    const int64_t b = bc / C;
+    y[i] = bf2f(x[(b * HW + pix) * C + c]);
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = f2bf(x[i]);
+}
+
+__global__ void cfg_step_kernel(const float* __restrict__ eps, int cfg, float g, const float* __restrict__ x,
+                                const float* __restrict__ noise, float* __restrict__ x_prev,
+                                float* __restrict__ eps_out, const float* __restrict__ coef,
+                                const int32_t* __restrict__ step_dev, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* cf = coef + 4 * (step_dev ? *step_dev : 0);
+    float e = eps[i];
+    if (cfg) e = e + g * (eps[n + i] - e);
+    if (eps_out) eps_out[i] = e;
+    if (x_prev) {
+        float v = cf[0] * x[i] + cf[1] * e;
+        if (noise) v += cf[2] * noise[i];
+        x_prev[i] = v;
+    }
+}
+
+struct LinArgs {
+    const float* x[6];
+    float c[6];
+};
+__global__ void lincomb_kernel(float* __restrict__ y, int nin, LinArgs a, const float* __restrict__ cdev, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int j = 0; j < nin; ++j) v += (cdev ? cdev[j] : a.c[j]) * a.x[j][i];
+    y[i] = v;
+}
+
+__global__ void advance_step_kernel(int32_t* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+
+inline dim3 grid1d(int64_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+}  // namespace
+
+extern "C" int pcdm_version(void) { return 1; }
+extern "C" int pcdm_is_emulator(void) {
+#ifdef PCDM_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+extern "C" int pcdm_timestep_embedding(const int64_t* t_dev, const int32_t* step_dev, float* out, int B, int dim,
+                                       int flip_sin_to_cos, float shift, pcdm_stream_t s) {
+    if (!t_dev || !out || B <= 0 || dim <= 0 || dim % 2) return -1;
+    PCDM_LAUNCH(timestep_embedding_kernel, grid1d((int64_t)B * dim, 256), dim3(256), 0, (hipStream_t)s, t_dev, step_dev,
+                out, B, dim, flip_sin_to_cos, shift);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_small_linear(const float* x, const void* w, const float* bias, const float* add, float* y, int B,
+                                 int K, int N, int act_in, int act_out, pcdm_stream_t s) {
+    if (!x || !w || !y || B <= 0 || B > 32 || K <= 0 || K % 8 || N <= 0) return -1;
+    PCDM_LAUNCH(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)s, x, (const u16*)w, bias, add, y,
+                B, K, N, act_in, act_out);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_assemble_input(const float* latents, int N, int rep, const float* mask, int mask_b,
+                                   const float* masked, int masked_b, void* out, int h, int w, int cpad,
+                                   pcdm_stream_t s) {
+    if (!latents || !mask || !masked || !out || N <= 0 || rep <= 0 || cpad % 8 || cpad < 16) return -1;
+    const int64_t total = (int64_t)N * rep * h * w * (cpad / 8);
+    PCDM_LAUNCH(assemble_input_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, latents, N, rep, mask, mask_b,
+                masked, masked_b, (u16*)out, h * w, cpad);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, pcdm_stream_t s) {
+    if (!x || !y || C % 8) return -1;
+    const int64_t total = (int64_t)B * HW * (C / 8);
+    PCDM_LAUNCH(nchw_to_nhwc_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, x, (u16*)y, C, HW, total);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_nhwc_bf16_to_nchw_f32(const void* x, float* y, int B, int C, int HW, pcdm_stream_t s) {
+    if (!x || !y) return -1;
+    const int64_t total = (int64_t)B * HW * C;
+    PCDM_LAUNCH(nhwc_to_nchw_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, (const u16*)x, y, C, HW, total);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_f32_to_bf16(const float* x, void* y, int64_t n, pcdm_stream_t s) {
+    if (!x || !y || n <= 0) return -1;
+    PCDM_LAUNCH(f32_to_bf16_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, x, (u16*)y, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x, const float* noise, float* x_prev,
+                             float* eps_out, const float* coef, const int32_t* step_dev, int64_t n, pcdm_stream_t s) {
+    if (!eps || n <= 0 || (x_prev && (!x || !coef))) return -1;
+    PCDM_LAUNCH(cfg_step_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, eps, cfg, g, x, noise, x_prev, eps_out,
+                coef, step_dev, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_lincomb(float* y, int nin, const float* const* xs, const float* c, int64_t n, pcdm_stream_t s) {
+    if (!y || nin <= 0 || nin > 6 || !xs || !c || n <= 0) return -1;
+    LinArgs a;
+    for (int i = 0; i < 6; ++i) {
+        a.x[i] = i < nin ? xs[i] : nullptr;
+        a.c[i] = i < nin ? c[i] : 0.f;
+    }
+    PCDM_LAUNCH(lincomb_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, y, nin, a, (const float*)nullptr, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s) {
+    if (!step_dev) return -1;
+    PCDM_LAUNCH(advance_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, step_dev);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}

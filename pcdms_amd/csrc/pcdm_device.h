@@ -1,0 +1,110 @@
+// Device-side helpers shared by every pcdm kernel (gfx950 / CDNA4, wave = 64).
+//
+// PCDM_EMU is defined ONLY by the test build (tests/emu): the same kernel sources are then
+// compiled for the host against a lane-level emulator so index logic can be checked on the
+// GPU-less dev container.  The product library is always built by hipcc for gfx950.
+#pragma once
+#include <stdint.h>
+
+#ifndef PCDM_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+typedef unsigned short u16;
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define PCDM_WAVE 64
+
+// ---- bf16 <-> f32 (bit exact, round-to-nearest-even; NaN preserved) ------------------------
+__device__ __forceinline__ float bf2f(u16 v) {
+    uint32_t u = ((uint32_t)v) << 16;
+    return __builtin_bit_cast(float, u);
+}
+__device__ __forceinline__ u16 f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+
+// ---- launch / dynamic LDS ------------------------------------------------------------------
+#ifdef PCDM_EMU
+#define PCDM_DYN_SMEM(name) char* name = emu::dyn_smem
+#define PCDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define PCDM_KERNEL_NAME(...) __VA_ARGS__
+#else
+#define PCDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define PCDM_KERNEL_NAME(...) __VA_ARGS__
+#define PCDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    kernel<<<(grid), (block), (smem), (stream)>>>(__VA_ARGS__)
+#endif
+
+// ---- math ----------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_exp2(float x) {
+#ifdef PCDM_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);  // v_exp_f32
+#endif
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+#ifdef PCDM_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// erf-based GELU (PyTorch F.gelu default, diffusers GEGLU)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---- MFMA (cdna_hip_programming.md §3 fragment maps) -----------------------------------------
+// 32x32x16 bf16:  A lane l -> row  (l&31), k = 8*(l>>5)+e ;  B lane l -> col (l&31), same k ;
+//                 D lane l, reg r -> col (l&31), row (r&3) + 8*(r>>2) + 4*(l>>5).
+__device__ __forceinline__ f32x16 mfma_32x32x16(u16x8 a, u16x8 b, f32x16 c) {
+#ifdef PCDM_EMU
+    struct P { u16 a[8], b[8]; } p;
+    for (int e = 0; e < 8; ++e) { p.a[e] = a[e]; p.b[e] = b[e]; }
+    const char* all = emu::wave_exchange(&p, sizeof(p));
+    const int l = emu::lane_id(), j = l & 31, hh = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float s = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const P* pa = (const P*)(all + (i + 32 * (k >> 3)) * emu::kSlot);
+            const P* pb = (const P*)(all + (j + 32 * (k >> 3)) * emu::kSlot);
+            s += bf2f(pa->a[k & 7]) * bf2f(pb->b[k & 7]);
+        }
+        d[r] = s;
+    }
+    return d;
+#else
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// ---- wave reductions -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+#define PCDM_CHECK_LAUNCH()                          \
+    do {                                             \
+        hipError_t e_ = hipGetLastError();           \
+        if (e_ != hipSuccess) return -(int)e_ - 1000; \
+    } while (0)

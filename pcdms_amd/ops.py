@@ -1,0 +1,273 @@
+"""Thin tensor-level wrappers over the C-ABI of libpcdm.so (include/pcdm.h).
+
+PyTorch is used for device memory and streams only; every op here is one call into the
+hand-written HIP library on the caller's current stream.  Tensors must live on a ROCm device
+(``cuda``); CPU tensors are accepted only when the loaded library is the test emulator build.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import GemmParams
+
+EPI_STORE, EPI_GEGLU, EPI_SPLIT_VT, EPI_NCHW_F32 = 0, 1, 2, 3
+BF16 = torch.bfloat16
+
+
+def _stream(t: torch.Tensor) -> Optional[int]:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if not _lib.is_emulator():
+        raise RuntimeError("pcdms_amd ops need tensors on the MI355X (device 'cuda'); there is no CPU path")
+    return None
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(rc: int, name: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def _c(t: torch.Tensor, dtype) -> torch.Tensor:
+    assert t.dtype == dtype and t.is_contiguous(), (t.dtype, dtype, t.is_contiguous())
+    return t
+
+
+# ------------------------------------------------------------------------------------ norms
+def groupnorm_ws(B: int, C: int, device) -> torch.Tensor:
+    n = _lib.lib().pcdm_groupnorm_ws_floats(B, C)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
+              gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
+    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16."""
+    C1 = x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    _c(x1, BF16); _c(out, BF16); _c(gamma, torch.float32); _c(beta, torch.float32)
+    assert ws.numel() >= _lib.lib().pcdm_groupnorm_ws_floats(B, C1 + C2)
+    rc = _lib.lib().pcdm_groupnorm(_ptr(x1), C1, _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
+                                  int(silu), _ptr(out), _ptr(ws), _stream(x1))
+    _chk(rc, "pcdm_groupnorm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
+    rows, Cc = x.shape
+    _c(x, BF16); _c(out, BF16)
+    _chk(_lib.lib().pcdm_layernorm(_ptr(x), _ptr(out), rows, Cc, eps, _ptr(gamma), _ptr(beta), _stream(x)),
+         "pcdm_layernorm")
+    return out
+
+
+# ------------------------------------------------------------------------------------ weights
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class PackedWeight:
+    """bf16 [Npad, K] (K contiguous) + fp32 bias[Npad] as the GEMM kernel wants them."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    N: int
+    K: int
+    Npad: int
+    cin: int = 0       # conv: (padded) input channels
+    geglu: bool = False
+
+
+def pack_linear(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: int = 64) -> PackedWeight:
+    """nn.Linear / 1x1-conv weight [N, K(,1,1)] -> packed."""
+    w = w.reshape(w.shape[0], -1).float()
+    N, K = w.shape
+    assert K % 64 == 0, K
+    Npad = _round_up(N, pad_to)
+    wp = torch.zeros(Npad, K, dtype=torch.float32)
+    wp[:N] = w
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(Npad, dtype=torch.float32)
+        bp[:N] = bias.float()
+        bp = bp.to(device)
+    return PackedWeight(wp.to(BF16).to(device), bp, N, K, Npad)
+
+
+def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: int = 64) -> PackedWeight:
+    """Conv2d weight [N, Cin, 3, 3] -> [Npad, 9*Cin_pad] with k = (ky*3+kx)*Cin_pad + c."""
+    N, Cin = w.shape[:2]
+    Cp = _round_up(Cin, 64)
+    wp = torch.zeros(N, 3, 3, Cp, dtype=torch.float32)
+    wp[..., :Cin] = w.float().permute(0, 2, 3, 1)
+    pw = pack_linear(wp.reshape(N, 9 * Cp), bias, device, pad_to)
+    pw.cin = Cp
+    return pw
+
+
+def pack_geglu(w: torch.Tensor, bias: torch.Tensor, device) -> PackedWeight:
+    """GEGLU proj weight [2*D, K] (rows [h | gate]) -> rows interleaved per 64 as [32 h | 32 gate]."""
+    w = w.float()
+    D2, K = w.shape
+    D = D2 // 2
+    Dp = _round_up(D, 64)
+    wh = torch.zeros(Dp, K); wh[:D] = w[:D]
+    wg = torch.zeros(Dp, K); wg[:D] = w[D:]
+    bh = torch.zeros(Dp); bh[:D] = bias[:D].float()
+    bg = torch.zeros(Dp); bg[:D] = bias[D:].float()
+    wp = torch.stack([wh.view(Dp // 32, 32, K), wg.view(Dp // 32, 32, K)], dim=1).reshape(2 * Dp, K)
+    bp = torch.stack([bh.view(Dp // 32, 32), bg.view(Dp // 32, 32)], dim=1).reshape(2 * Dp)
+    return PackedWeight(wp.to(BF16).to(device), bp.to(device), D, K, 2 * Dp, geglu=True)
+
+
+# ------------------------------------------------------------------------------------ GEMM / conv
+def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
+         rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
+         residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
+         out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
+         use_bias: bool = True) -> torch.Tensor:
+    """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
+    NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``."""
+    p = GemmParams()
+    _c(a, BF16)
+    p.a = _ptr(a)
+    if conv is not None:
+        p.conv = 1
+        p.B, p.Hi, p.Wi, p.Ho, p.Wo = conv["B"], conv["Hi"], conv["Wi"], conv["Ho"], conv["Wo"]
+        p.stride, p.upsample, p.cin = conv.get("stride", 1), conv.get("upsample", 0), pw.cin
+        assert a.numel() == p.B * p.Hi * p.Wi * pw.cin, (a.shape, pw.cin)
+        M = p.B * p.Ho * p.Wo
+    else:
+        M = a.shape[0]
+        p.lda = a.stride(0)
+        p.c1 = a.shape[1]
+        if a2 is not None:
+            _c(a2, BF16)
+            p.a2 = _ptr(a2)
+            p.lda2 = a2.stride(0)
+            assert a.shape[1] + a2.shape[1] == pw.K
+        else:
+            assert a.shape[1] == pw.K, (a.shape, pw.K)
+    p.w = _ptr(pw.w)
+    p.M, p.N, p.K, p.Npad = M, pw.N, pw.K, pw.Npad
+    p.bias = _ptr(pw.bias) if (use_bias and pw.bias is not None) else None
+    p.rows_per_batch = rows_per_batch or M
+    if rowvec is not None:
+        _c(rowvec, torch.float32)
+        assert rowvec.shape[-1] == pw.N
+        p.rowvec = _ptr(rowvec)
+    if residual is not None:
+        _c(residual, BF16)
+        p.residual = _ptr(residual)
+        p.ldr = residual.stride(0) if residual.dim() == 2 else pw.N
+        p.res_mod = res_mod
+    p.epilogue = epilogue
+    p.vt_col0 = vt_col0
+    p.out = _ptr(out)
+    p.ldo = out.stride(0) if (out.dim() == 2 and epilogue != EPI_NCHW_F32) else pw.N
+    if out2 is not None:
+        p.out2 = _ptr(out2)
+        p.ldo2 = out2.shape[-1]
+    p.tile = tile
+    _chk(_lib.lib().pcdm_gemm(C.byref(p), _stream(a)), "pcdm_gemm")
+    return out
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,
+               Lk: int, scale: Optional[float] = None) -> torch.Tensor:
+    """q [B*Lq, ldq], k [B*Lk, ldk] (views allowed: row stride = .stride(0)), vt [B, H*64, ldvt], out [B*Lq, ldo]."""
+    for t in (q, k, vt, out):
+        assert t.dtype == BF16
+    assert q.stride(1) == 1 and k.stride(1) == 1 and vt.is_contiguous() and out.stride(1) == 1
+    scale = scale if scale is not None else 1.0 / math.sqrt(64)
+    rc = _lib.lib().pcdm_flash_attn(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out),
+                                   out.stride(0), B, H, Lq, Lk, scale, _stream(q))
+    _chk(rc, "pcdm_flash_attn")
+    return out
+
+
+# ------------------------------------------------------------------------------------ small ops
+def timestep_embedding(t_dev: torch.Tensor, step_dev: Optional[torch.Tensor], out: torch.Tensor, flip: bool = True,
+                       shift: float = 0.0) -> torch.Tensor:
+    assert t_dev.dtype == torch.int64 and out.dtype == torch.float32
+    B, dim = out.shape
+    _chk(_lib.lib().pcdm_timestep_embedding(_ptr(t_dev), _ptr(step_dev), _ptr(out), B, dim, int(flip), shift,
+                                            _stream(out)), "pcdm_timestep_embedding")
+    return out
+
+
+def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
+                 add: Optional[torch.Tensor] = None, act_in: bool = False, act_out: bool = False) -> torch.Tensor:
+    """x fp32 [B,K], w bf16 [N,K] -> out fp32 [B,N]."""
+    _c(x, torch.float32); _c(w, BF16); _c(out, torch.float32)
+    B, K = x.shape
+    N = w.shape[0]
+    _chk(_lib.lib().pcdm_small_linear(_ptr(x), _ptr(w), _ptr(bias), _ptr(add), _ptr(out), B, K, N, int(act_in),
+                                      int(act_out), _stream(x)), "pcdm_small_linear")
+    return out
+
+
+def assemble_input(latents: torch.Tensor, rep: int, mask: torch.Tensor, masked: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """latents fp32 [N,4,h,w]; mask [1|rep*N,1,h,w]; masked [1|rep*N,4,h,w] -> out bf16 [rep*N,h,w,cpad]."""
+    N, _, h, w = latents.shape
+    _c(latents, torch.float32); _c(mask, torch.float32); _c(masked, torch.float32); _c(out, BF16)
+    cpad = out.shape[-1]
+    _chk(_lib.lib().pcdm_assemble_input(_ptr(latents), N, rep, _ptr(mask), mask.shape[0], _ptr(masked),
+                                        masked.shape[0], _ptr(out), h, w, cpad, _stream(out)), "pcdm_assemble_input")
+    return out
+
+
+def nchw_to_nhwc_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, Cc, H, W = x.shape
+    x = _c(x.float().contiguous(), torch.float32)
+    if out is None:
+        out = torch.empty(B, H, W, Cc, dtype=BF16, device=x.device)
+    _chk(_lib.lib().pcdm_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(out), B, Cc, H * W, _stream(x)), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_bf16_to_nchw(x: torch.Tensor, B: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    _chk(_lib.lib().pcdm_nhwc_bf16_to_nchw_f32(_ptr(_c(x, BF16)), _ptr(out), B, Cc, H * W, _stream(x)), "nhwc_to_nchw")
+    return out
+
+
+def f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _c(x, torch.float32)
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _chk(_lib.lib().pcdm_f32_to_bf16(_ptr(x), _ptr(out), x.numel(), _stream(x)), "f32_to_bf16")
+    return out
+
+
+def cfg_step(eps: torch.Tensor, cfg: bool, g: float, x: Optional[torch.Tensor], x_prev: Optional[torch.Tensor],
+             coef: Optional[torch.Tensor], step_dev: Optional[torch.Tensor] = None,
+             noise: Optional[torch.Tensor] = None, eps_out: Optional[torch.Tensor] = None) -> None:
+    n = eps.numel() // (2 if cfg else 1)
+    _c(eps, torch.float32)
+    _chk(_lib.lib().pcdm_cfg_step(_ptr(eps), int(cfg), g, _ptr(x), _ptr(noise), _ptr(x_prev), _ptr(eps_out),
+                                  _ptr(coef), _ptr(step_dev), n, _stream(eps)), "pcdm_cfg_step")
+
+
+def lincomb(out: torch.Tensor, xs: Sequence[torch.Tensor], cs: Sequence[float]) -> torch.Tensor:
+    n = len(xs)
+    assert 1 <= n <= 6 and len(cs) == n
+    for t in xs:
+        _c(t, torch.float32)
+        assert t.numel() == out.numel()
+    arr = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    carr = (C.c_float * n)(*[float(c) for c in cs])
+    _chk(_lib.lib().pcdm_lincomb(_ptr(out), n, arr, carr, out.numel(), _stream(out)), "pcdm_lincomb")
+    return out
+
+
+def advance_step(step_dev: torch.Tensor) -> None:
+    _chk(_lib.lib().pcdm_advance_step(_ptr(step_dev), _stream(step_dev)), "pcdm_advance_step")

@@ -1,0 +1,315 @@
+"""Per-kernel parity: every C-ABI op of libpcdm vs a plain PyTorch fp32 reference of the same op.
+
+Each test runs under the lane emulator on tiny shapes (CPU suite) and on the MI355X (``-m gpu``) on
+larger, awkward shapes (ragged M, non-power-of-two widths such as 88/44/22/11, 258 context tokens).
+Inputs are rounded to bf16 first so the only error is fp32 accumulation order + the final bf16
+rounding: tolerance = 1% relative + 1% of the output scale (bf16 has 8 mantissa bits: 0.4%).
+"""
+from __future__ import annotations
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pcdms_amd import ops
+
+BF16 = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF16)
+
+
+def close(out, ref, tol=1e-2):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all()
+    s = ref.abs().max().item() + 1e-6
+    err = (out - ref).abs().max().item()
+    assert err <= tol * s + tol * 0, f"max err {err:.4g} vs scale {s:.4g}"
+    rel = ((out - ref).norm() / (ref.norm() + 1e-12)).item()
+    assert rel < tol, f"rel-L2 {rel:.4g}"
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("case", ["single", "concat_straddle", "wide"])
+def test_groupnorm(backend, case):
+    dev = backend.device
+    if case == "single":
+        B, HW, C1, C2, G = (2, 37, 64, 0, 32) if backend.is_emu else (8, 64 * 88, 320, 0, 32)
+    elif case == "concat_straddle":  # group size 30: groups straddle the x1|x2 boundary (up-block 640+320)
+        B, HW, C1, C2, G = (2, 19, 64, 32, 32) if backend.is_emu else (8, 32 * 44, 640, 320, 32)
+    else:
+        B, HW, C1, C2, G = (1, 11, 256, 256, 32) if backend.is_emu else (8, 16 * 22, 1280, 1280, 32)
+    x1 = rnd(B * HW, C1, seed=1) + 0.5
+    x2 = rnd(B * HW, C2, seed=2) * 2 if C2 else None
+    C = C1 + C2
+    gamma = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5
+    beta = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2
+    for silu in (False, True):
+        out = torch.empty(B * HW, C, dtype=BF16, device=dev)
+        ws = ops.groupnorm_ws(B, C, dev)
+        ops.groupnorm(x1.to(dev), None if x2 is None else x2.to(dev), B, HW, G, 1e-5, gamma.to(dev), beta.to(dev), silu,
+                      out, ws)
+        backend.sync()
+        xx = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+        xr = xx.view(B, HW, C).permute(0, 2, 1)  # [B, C, HW]
+        ref = F.group_norm(xr, G, gamma, beta, 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        close(out.view(B, HW, C), ref.permute(0, 2, 1))
+
+
+def test_layernorm(backend):
+    dev = backend.device
+    for rows, C in ([(9, 64), (5, 320)] if backend.is_emu else [(8 * 5632, 320), (2816, 1280), (703, 640)]):
+        x = rnd(rows, C, seed=5) * 3 + 1
+        gamma = torch.rand(C, generator=torch.Generator().manual_seed(6)) + 0.5
+        beta = torch.randn(C, generator=torch.Generator().manual_seed(7))
+        out = torch.empty(rows, C, dtype=BF16, device=dev)
+        ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, out)
+        backend.sync()
+        close(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm_sizes(backend):
+    # (M, K, N, tile)
+    if backend.is_emu:
+        return [(70, 128, 64, 2), (200, 64, 192, 3), (130, 128, 128, 1)]
+    return [(45056, 320, 320, 0), (2816, 1280, 1280, 0), (704, 1280, 1280, 0), (11264, 640, 1920, 0),
+            (1000, 192, 320, 1 - 1), (777, 2560, 640, 3), (777, 2560, 640, 2), (4096, 1024, 1024, 1)]
+
+
+def test_gemm_linear_bias_residual_rowvec(backend):
+    dev = backend.device
+    for (M, K, N, tile) in _gemm_sizes(backend):
+        rpb = 7 if M % 7 == 0 else (M // 2 if M % 2 == 0 else M)
+        a = rnd(M, K, seed=10)
+        w = rnd(N, K, seed=11, scale=1 / math.sqrt(K))
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(12))
+        res = rnd(M, N, seed=13)
+        rowvec = torch.randn(M // rpb, N, generator=torch.Generator().manual_seed(14))
+        pw = ops.pack_linear(w.float(), bias, dev)
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.gemm(a.to(dev), pw, out, rowvec=rowvec.to(dev), rows_per_batch=rpb, residual=res.to(dev), res_mod=M, tile=tile)
+        backend.sync()
+        ref = a.float() @ w.float().t() + bias + res.float() + rowvec.repeat_interleave(rpb, 0)
+        close(out, ref)
+
+
+def test_gemm_two_source_and_broadcast_residual(backend):
+    dev = backend.device
+    M, K1, K2, N = (96, 64, 128, 64) if backend.is_emu else (11264, 1280, 640, 640)
+    a1, a2 = rnd(M, K1, seed=20), rnd(M, K2, seed=21)
+    w = rnd(N, K1 + K2, seed=22, scale=1 / math.sqrt(K1 + K2))
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(23))
+    rm = M // 2
+    res = rnd(rm, N, seed=24)  # broadcast over 2 "batches" (pose feature add)
+    pw = ops.pack_linear(w.float(), bias, dev)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(a1.to(dev), pw, out, a2=a2.to(dev), residual=res.to(dev), res_mod=rm)
+    backend.sync()
+    ref = torch.cat([a1, a2], 1).float() @ w.float().t() + bias + res.float().repeat(2, 1)
+    close(out, ref)
+
+
+def test_gemm_geglu(backend):
+    dev = backend.device
+    M, K, D = (70, 64, 96) if backend.is_emu else (11264, 640, 2560)
+    a = rnd(M, K, seed=30)
+    w = rnd(2 * D, K, seed=31, scale=1 / math.sqrt(K))
+    bias = torch.randn(2 * D, generator=torch.Generator().manual_seed(32)) * 0.5
+    pw = ops.pack_geglu(w.float(), bias, dev)
+    out = torch.empty(M, D, dtype=BF16, device=dev)
+    ops.gemm(a.to(dev), pw, out, epilogue=ops.EPI_GEGLU)
+    backend.sync()
+    pr = a.float() @ w.float().t() + bias
+    h, g = pr.chunk(2, -1)
+    close(out, h * F.gelu(g))
+
+
+def test_gemm_split_vt_and_nchw(backend):
+    dev = backend.device
+    B, L, K, Cc = (2, 37, 64, 64) if backend.is_emu else (8, 1408, 640, 640)
+    M = B * L
+    Lp = (L + 7) // 8 * 8
+    a = rnd(M, K, seed=40)
+    w = rnd(3 * Cc, K, seed=41, scale=1 / math.sqrt(K))
+    pw = ops.pack_linear(w.float(), None, dev)
+    qk = torch.empty(M, 2 * Cc, dtype=BF16, device=dev)
+    vt = torch.zeros(B, Cc, Lp, dtype=BF16, device=dev)
+    ops.gemm(a.to(dev), pw, qk, rows_per_batch=L, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * Cc)
+    backend.sync()
+    ref = a.float() @ w.float().t()
+    close(qk, ref[:, : 2 * Cc])
+    close(vt[:, :, :L], ref[:, 2 * Cc:].view(B, L, Cc).permute(0, 2, 1))
+    assert (vt[:, :, L:] == 0).all()
+    # NCHW fp32 output with N = 4 (conv_out shape class)
+    w4 = rnd(4, K, seed=42, scale=1 / math.sqrt(K))
+    b4 = torch.randn(4, generator=torch.Generator().manual_seed(43))
+    pw4 = ops.pack_linear(w4.float(), b4, dev)
+    o4 = torch.empty(B, 4, L, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), pw4, o4, rows_per_batch=L, epilogue=ops.EPI_NCHW_F32)
+    backend.sync()
+    ref4 = (a.float() @ w4.float().t() + b4).view(B, L, 4).permute(0, 2, 1)
+    close(o4, ref4, tol=2e-3)
+
+
+@pytest.mark.parametrize("mode", ["s1", "s2", "up"])
+def test_conv3x3(backend, mode):
+    dev = backend.device
+    if backend.is_emu:
+        B, H, W, Cin, Cout = 2, 6, 5, 64, 64
+    else:
+        B, H, W, Cin, Cout = (8, 32, 44, 640, 640) if mode != "up" else (8, 16, 22, 1280, 1280)
+    x = rnd(B, Cin, H, W, seed=50)
+    w = rnd(Cout, Cin, 3, 3, seed=51, scale=1 / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(52))
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    if mode == "s1":
+        Ho, Wo, st, up = H, W, 1, 0
+        ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    elif mode == "s2":
+        Ho, Wo, st, up = (H - 1) // 2 + 1, (W - 1) // 2 + 1, 2, 0
+        ref = F.conv2d(x.float(), w.float(), bias, stride=2, padding=1)
+    else:
+        Ho, Wo, st, up = 2 * H, 2 * W, 1, 1
+        ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1)
+    pw = ops.pack_conv3x3(w.float(), bias, dev)
+    temb = torch.randn(B, Cout, generator=torch.Generator().manual_seed(53))
+    out = torch.empty(B * Ho * Wo, Cout, dtype=BF16, device=dev)
+    ops.gemm(xh.to(dev), pw, out, conv=dict(B=B, Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=st, upsample=up),
+             rowvec=temb.to(dev), rows_per_batch=Ho * Wo)
+    backend.sync()
+    ref = ref + temb[:, :, None, None]
+    close(out.view(B, Ho, Wo, Cout), ref.permute(0, 2, 3, 1))
+
+
+def test_conv_in_padded_channels(backend):
+    """conv_in: 9 input channels zero-padded to 64 (weights too) == the 9-channel conv."""
+    dev = backend.device
+    B, H, W, Cout = (1, 4, 6, 64) if backend.is_emu else (8, 64, 88, 320)
+    x = rnd(B, 9, H, W, seed=60)
+    w = rnd(Cout, 9, 3, 3, seed=61, scale=1 / 9)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(62))
+    pw = ops.pack_conv3x3(w.float(), bias, dev)
+    assert pw.cin == 64
+    xh = torch.zeros(B, H, W, 64, dtype=BF16)
+    xh[..., :9] = x.permute(0, 2, 3, 1)
+    out = torch.empty(B * H * W, Cout, dtype=BF16, device=dev)
+    ops.gemm(xh.to(dev), pw, out, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W))
+    backend.sync()
+    close(out.view(B, H, W, Cout), F.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, B, H, Lq, Lk):
+    qh = q.float().view(B, Lq, H, 64).transpose(1, 2)
+    kh = k.float().view(B, Lk, H, 64).transpose(1, 2)
+    vh = v.float().view(B, Lk, H, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) / 8.0
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * Lq, H * 64)
+
+
+@pytest.mark.parametrize("case", ["self", "cross258", "tiny88", "spike"])
+def test_flash_attn(backend, case):
+    dev = backend.device
+    if backend.is_emu:
+        B, H, Lq, Lk = {"self": (1, 2, 70, 70), "cross258": (1, 1, 40, 66), "tiny88": (2, 1, 24, 24),
+                        "spike": (1, 1, 33, 130)}[case]
+    else:
+        B, H, Lq, Lk = {"self": (8, 5, 5632, 5632), "cross258": (8, 10, 1408, 258), "tiny88": (8, 20, 88, 88),
+                        "spike": (2, 5, 1408, 1408)}[case]
+    Cc = H * 64
+    q, k, v = rnd(B * Lq, Cc, seed=70), rnd(B * Lk, Cc, seed=71), rnd(B * Lk, Cc, seed=72)
+    if case == "spike":  # force large running-max jumps late in the key sequence (online-softmax rescale)
+        k = k.clone()
+        k[Lk - 3] = (q[5].float() * 6).to(BF16)
+        k[Lk // 2] = (q[7].float() * 3).to(BF16)
+    Lp = (Lk + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, Lp, dtype=BF16)
+    vt[:, :, :Lk] = v.view(B, Lk, Cc).permute(0, 2, 1)
+    # q / k as strided views of a fused buffer, like the UNet does
+    qk = torch.zeros(B * max(Lq, Lk), 2 * Cc, dtype=BF16)
+    qk[: B * Lq, :Cc] = q
+    qk[: B * Lk, Cc:] = k
+    qk = qk.to(dev)
+    out = torch.empty(B * Lq, Cc, dtype=BF16, device=dev)
+    ops.flash_attn(qk[: B * Lq, :Cc], qk[: B * Lk, Cc:], vt.to(dev), out, B, H, Lq, Lk)
+    backend.sync()
+    close(out, _attn_ref(q, k, v, B, H, Lq, Lk), tol=1.5e-2)
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+def test_timestep_embedding_and_small_linear(backend):
+    dev = backend.device
+    from oracle.unet import timestep_embedding
+    B, dim = 4, 64 if backend.is_emu else 320
+    ts = torch.tensor([981, 961, 1, 500], dtype=torch.int64, device=dev)
+    for idx in (0, 2, 3):
+        step = torch.tensor([idx], dtype=torch.int32, device=dev)
+        out = torch.empty(B, dim, dtype=torch.float32, device=dev)
+        ops.timestep_embedding(ts, step, out)
+        backend.sync()
+        ref = timestep_embedding(ts[idx].cpu().expand(B), dim)
+        assert (out.cpu() - ref).abs().max() < 2e-4
+    K, N = (64, 40) if backend.is_emu else (1280, 20160)
+    x = torch.randn(B, K, generator=torch.Generator().manual_seed(80))
+    w = rnd(N, K, seed=81, scale=1 / math.sqrt(K))
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(82))
+    add = torch.randn(B, N, generator=torch.Generator().manual_seed(83))
+    for act_in, act_out in ((False, False), (True, False), (False, True)):
+        out = torch.empty(B, N, dtype=torch.float32, device=dev)
+        ops.small_linear(x.to(dev), w.to(dev), bias.to(dev), out, add=add.to(dev), act_in=act_in, act_out=act_out)
+        backend.sync()
+        xi = F.silu(x) if act_in else x
+        ref = xi @ w.float().t() + bias
+        ref = (F.silu(ref) if act_out else ref) + add
+        assert (out.cpu() - ref).abs().max() < 2e-3
+
+
+def test_assemble_cfg_step_lincomb_layout(backend):
+    dev = backend.device
+    N, h, w = (2, 4, 6) if backend.is_emu else (4, 64, 88)
+    g = torch.Generator().manual_seed(90)
+    lat = torch.randn(N, 4, h, w, generator=g)
+    mask = torch.cat([torch.ones(1, 1, h, w // 2), torch.zeros(1, 1, h, w // 2)], 3)
+    masked = torch.randn(1, 4, h, w, generator=g)
+    out = torch.empty(2 * N, h, w, 64, dtype=BF16, device=dev)
+    ops.assemble_input(lat.to(dev), 2, mask.to(dev), masked.to(dev), out)
+    backend.sync()
+    ref = torch.cat([torch.cat([lat] * 2), mask.expand(2 * N, -1, -1, -1), masked.expand(2 * N, -1, -1, -1)], 1)
+    o = out.float().cpu()
+    assert torch.equal(o[..., :9], ref.to(BF16).float().permute(0, 2, 3, 1))
+    assert (o[..., 9:] == 0).all()
+    # layout conversions round-trip
+    x = torch.randn(2, 16, h, w, generator=g)
+    xh = ops.nchw_to_nhwc_bf16(x.to(dev))
+    back = ops.nhwc_bf16_to_nchw(xh, 2, 16, h, w)
+    backend.sync()
+    assert torch.equal(back.cpu(), x.to(BF16).float())
+    assert torch.equal(ops.f32_to_bf16(x.to(dev)).cpu(), x.to(BF16))
+    # CFG + step with device-side coefficient table
+    eps = torch.randn(2 * N, 4, h, w, generator=g)
+    coef = torch.tensor([[9., 9., 9., 0.], [1.25, -0.5, 0.3, 0.]], dtype=torch.float32)
+    step = torch.tensor([1], dtype=torch.int32, device=dev)
+    noise = torch.randn(N, 4, h, w, generator=g)
+    xp = torch.empty(N, 4, h, w, dtype=torch.float32, device=dev)
+    eo = torch.empty_like(xp)
+    ops.cfg_step(eps.to(dev), True, 2.0, lat.to(dev), xp, coef.to(dev), step, noise=noise.to(dev), eps_out=eo)
+    ops.advance_step(step)
+    backend.sync()
+    assert int(step.item()) == 2
+    u, c = eps.chunk(2)
+    e = u + 2.0 * (c - u)
+    assert torch.allclose(eo.cpu(), e, atol=1e-6)
+    assert torch.allclose(xp.cpu(), 1.25 * lat - 0.5 * e + 0.3 * noise, atol=1e-5)
+    y = torch.empty_like(xp)
+    ops.lincomb(y, [xp, eo, noise.to(dev)], [0.5, -2.0, 3.0])
+    backend.sync()
+    assert torch.allclose(y.cpu(), 0.5 * xp.cpu() - 2 * eo.cpu() + 3 * noise, atol=1e-5)
