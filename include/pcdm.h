@@ -62,7 +62,8 @@ typedef struct pcdm_gemm_params {
     const void* w;
     int32_t M, N, K, Npad;
     const float* bias;
-    const float* rowvec;
+    const float* rowvec;   /* fp32 [M / rows_per_batch, ldrv] */
+    int64_t ldrv;          /* 0 -> N */
     int32_t rows_per_batch;
     const void* residual;
     int64_t ldr;
@@ -102,7 +103,7 @@ int pcdm_small_linear(const float* x, const void* w, const float* bias, const fl
 int pcdm_assemble_input(const float* latents, int N, int rep, const float* mask, int mask_b, const float* masked,
                         int masked_b, void* out, int h, int w, int cpad, pcdm_stream_t s);
 /* NCHW fp32 -> NHWC bf16 (pose feature st_pose_f, ref :430-431) and back. */
-int pcdm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, pcdm_stream_t s);
+int pcdm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int Cpad, int HW, pcdm_stream_t s); /* y [B,HW,Cpad], c >= C zero */
 int pcdm_nhwc_bf16_to_nchw_f32(const void* x, float* y, int B, int C, int HW, pcdm_stream_t s);
 int pcdm_f32_to_bf16(const float* x, void* y, int64_t n, pcdm_stream_t s);
 

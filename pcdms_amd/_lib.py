@@ -27,7 +27,7 @@ class GemmParams(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("cin", C.c_int32),
         ("w", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("Npad", C.c_int32),
-        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rows_per_batch", C.c_int32),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ldrv", C.c_int64), ("rows_per_batch", C.c_int32),
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("res_mod", C.c_int32),
         ("epilogue", C.c_int32), ("vt_col0", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out2", C.c_void_p), ("ldo2", C.c_int64),
@@ -47,7 +47,7 @@ _SIGS = {
     "pcdm_timestep_embedding": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_small_linear": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "pcdm_assemble_input": ([_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P], C.c_int),
-    "pcdm_nchw_f32_to_nhwc_bf16": ([_P, _P, _I, _I, _I, _P], C.c_int),
+    "pcdm_nchw_f32_to_nhwc_bf16": ([_P, _P, _I, _I, _I, _I, _P], C.c_int),
     "pcdm_nhwc_bf16_to_nchw_f32": ([_P, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_f32_to_bf16": ([_P, _P, _L, _P], C.c_int),
     "pcdm_cfg_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),

@@ -274,7 +274,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.Npad = p->Npad;
     a.bias = p->bias;
     a.rowvec = p->rowvec;
-    a.ldrv = p->N;
+    a.ldrv = p->ldrv > 0 ? (int)p->ldrv : p->N;
     a.rows_per_batch = p->rows_per_batch;
     a.residual = (const u16*)p->residual;
     a.ldr = p->ldr;

@@ -91,17 +91,21 @@ __global__ void assemble_input_kernel(const float* __restrict__ latents, int N, 
     *(u16x8*)(out + i * 8) = o;
 }
 
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, u16* __restrict__ y, int C, int HW, int64_t total) {
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, u16* __restrict__ y, int C, int Cpad, int HW,
+                                    int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, pixel, octet)
     if (i >= total) return;
-    const int noct = C / 8;
+    const int noct = Cpad / 8;
     const int oc = (int)(i % noct);
     const int64_t bp = i / noct;
     const int pix = (int)(bp % HW);
     const int64_t b = bp / HW;
     u16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(x[(b * C + oc * 8 + e) * HW + pix]);
+    for (int e = 0; e < 8; ++e) {
+        const int c = oc * 8 + e;
+        o[e] = c < C ? f2bf(x[(b * C + c) * HW + pix]) : (u16)0;
+    }
     *(u16x8*)(y + i * 8) = o;
 }
 
@@ -194,10 +198,10 @@ extern "C" int pcdm_assemble_input(const float* latents, int N, int rep, const f
     return 0;
 }
 
-extern "C" int pcdm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, pcdm_stream_t s) {
-    if (!x || !y || C % 8) return -1;
-    const int64_t total = (int64_t)B * HW * (C / 8);
-    PCDM_LAUNCH(nchw_to_nhwc_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, x, (u16*)y, C, HW, total);
+extern "C" int pcdm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int Cpad, int HW, pcdm_stream_t s) {
+    if (!x || !y || Cpad % 8 || Cpad < C) return -1;
+    const int64_t total = (int64_t)B * HW * (Cpad / 8);
+    PCDM_LAUNCH(nchw_to_nhwc_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, x, (u16*)y, C, Cpad, HW, total);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -161,9 +161,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     p.bias = _ptr(pw.bias) if (use_bias and pw.bias is not None) else None
     p.rows_per_batch = rows_per_batch or M
     if rowvec is not None:
-        _c(rowvec, torch.float32)
-        assert rowvec.shape[-1] == pw.N
+        assert rowvec.dtype == torch.float32 and rowvec.shape[-1] == pw.N and rowvec.stride(-1) == 1
         p.rowvec = _ptr(rowvec)
+        p.ldrv = rowvec.stride(0)
     if residual is not None:
         _c(residual, BF16)
         p.residual = _ptr(residual)
@@ -225,12 +225,15 @@ def assemble_input(latents: torch.Tensor, rep: int, mask: torch.Tensor, masked: 
     return out
 
 
-def nchw_to_nhwc_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def nchw_to_nhwc_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, cpad: Optional[int] = None) -> torch.Tensor:
+    """NCHW (any float dtype) -> NHWC bf16, channels zero-padded to ``cpad``."""
     B, Cc, H, W = x.shape
     x = _c(x.float().contiguous(), torch.float32)
+    cpad = cpad or _round_up(Cc, 8)
     if out is None:
-        out = torch.empty(B, H, W, Cc, dtype=BF16, device=x.device)
-    _chk(_lib.lib().pcdm_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(out), B, Cc, H * W, _stream(x)), "nchw_to_nhwc")
+        out = torch.empty(B, H, W, cpad, dtype=BF16, device=x.device)
+    assert out.shape[-1] == cpad
+    _chk(_lib.lib().pcdm_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(out), B, Cc, cpad, H * W, _stream(x)), "nchw_to_nhwc")
     return out
 
 

@@ -1,0 +1,646 @@
+"""MI355X-native stand-in for the reference's ``pipe.unet``.
+
+Mirrors the interface of ``Stage2_InapintUNet2DConditionModel``
+(/root/reference/src/models/stage2_inpaint_unet_2d_condition.py:61; ctor :66-448, forward
+:579-825) as used by the drivers (stage2_batchtest_inpaint_model.py:125-133) and pipelines
+(src/pipelines/stage2_inpaint_pipeline.py:504-506): ``from_pretrained`` / ``load_state_dict`` with
+diffusers key names / ``.to`` / ``.config`` / ``forward(sample, timestep, encoder_hidden_states,
+class_labels, ..., my_pose_cond, return_dict)``.
+
+Nothing in here computes with PyTorch: the forward is a schedule of calls into libpcdm.so
+(hand-written gfx950 HIP, include/pcdm.h) on the current stream.  Activations are NHWC bf16; all
+scratch buffers are preallocated per input shape (static addresses => the whole step can be captured
+in a hipGraph by the pipeline).  Step-invariant work (class embedding, pose layout change,
+cross-attention K/V of the context) is cached on the identity of the
+input tensors.
+"""
+from __future__ import annotations
+
+import json
+import math
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Any, Dict, Iterator, List, Optional, Tuple, Union
+
+import torch
+
+from . import ops
+from .ops import BF16, PackedWeight
+
+_DEFAULT_CONFIG: Dict[str, Any] = dict(
+    sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    mid_block_type="UNetMidBlock2DCrossAttn",
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    only_cross_attention=False, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    downsample_padding=1, mid_block_scale_factor=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-5,
+    cross_attention_dim=1280, encoder_hid_dim=None, encoder_hid_dim_type=None, attention_head_dim=8,
+    num_attention_heads=None, dual_cross_attention=False, use_linear_projection=False, class_embed_type=None,
+    addition_embed_type=None, num_class_embeds=None, upcast_attention=False, resnet_time_scale_shift="default",
+    resnet_skip_time_act=False, resnet_out_scale_factor=1.0, time_embedding_type="positional",
+    time_embedding_dim=None, time_embedding_act_fn=None, timestep_post_act=None, time_cond_proj_dim=None,
+    conv_in_kernel=3, conv_out_kernel=3, projection_class_embeddings_input_dim=None,
+    class_embeddings_concat=False, mid_block_only_cross_attention=None, cross_attention_norm=None,
+    addition_embed_type_num_heads=64,
+)
+
+# SD-2.1-base ``unet/config.json``; used when no config.json is on disk.
+SD21_BASE_UNET_CONFIG: Dict[str, Any] = dict(
+    sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True,
+    norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0, act_fn="silu",
+    _diffusers_version="0.24.0",
+)
+
+# values of the reference ctor this implementation supports (anything else -> NotImplementedError)
+_REQUIRED = dict(center_input_sample=False, mid_block_type="UNetMidBlock2DCrossAttn", only_cross_attention=False,
+                 act_fn="silu", encoder_hid_dim=None, encoder_hid_dim_type=None, dual_cross_attention=False,
+                 addition_embed_type=None, num_class_embeds=None, resnet_time_scale_shift="default",
+                 resnet_skip_time_act=False, time_embedding_type="positional", time_embedding_act_fn=None,
+                 timestep_post_act=None, time_cond_proj_dim=None, conv_in_kernel=3, conv_out_kernel=3,
+                 class_embeddings_concat=False, cross_attention_norm=None, downsample_padding=1)
+
+
+class UNet2DConditionOutput:
+    """``diffusers.models.unet_2d_condition.UNet2DConditionOutput`` stand-in (attribute + index access)."""
+
+    def __init__(self, sample: torch.Tensor):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+    def to_tuple(self):
+        return (self.sample,)
+
+
+class _Config(SimpleNamespace):
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def get(self, k, d=None):
+        return getattr(self, k, d)
+
+    def keys(self):
+        return self.__dict__.keys()
+
+
+def _as_tuple(v, n):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
+
+
+class Stage2_InapintUNet2DConditionModel:
+    """Drop-in for the reference class of the same (sic) name; inference only."""
+
+    def __init__(self, **kwargs):
+        cfg = dict(_DEFAULT_CONFIG)
+        unknown = [k for k in kwargs if k not in cfg and not k.startswith("_")]
+        if unknown:
+            raise TypeError(f"unexpected config keys: {unknown}")
+        cfg.update(kwargs)
+        for k, v in _REQUIRED.items():
+            if cfg[k] != v and not (k == "only_cross_attention" and not any(_as_tuple(cfg[k], 1))):
+                raise NotImplementedError(f"config {k}={cfg[k]!r} is outside the stage-2 hot path (supported: {v!r})")
+        if cfg["class_embed_type"] not in (None, "projection"):
+            raise NotImplementedError(f"class_embed_type={cfg['class_embed_type']!r}")
+        if cfg["class_embed_type"] == "projection" and cfg["projection_class_embeddings_input_dim"] is None:
+            raise ValueError("`class_embed_type`: 'projection' requires `projection_class_embeddings_input_dim` be set")
+        n = len(cfg["down_block_types"])
+        if len(cfg["up_block_types"]) != n or len(cfg["block_out_channels"]) != n:
+            raise ValueError("Must provide the same number of down/up block types and block_out_channels")
+        cfg.setdefault("_class_name", "Stage2_InapintUNet2DConditionModel")
+        cfg.setdefault("_diffusers_version", "0.24.0")
+        self.config = _Config(**cfg)
+        heads = cfg["num_attention_heads"] or cfg["attention_head_dim"]  # ref :122-128 (mis-named head COUNT)
+        self._heads = _as_tuple(heads, n)
+        self._boc = tuple(cfg["block_out_channels"])
+        self._layers = _as_tuple(cfg["layers_per_block"], n)
+        if len(set(self._layers)) != 1:
+            raise NotImplementedError("per-block layers_per_block")
+        for c, h in zip(self._boc, self._heads):
+            if c % h or c // h != 64:
+                raise NotImplementedError(f"attention head size {c}/{h} != 64 (the HIP attention kernel is head_dim 64)")
+            if c % 64:
+                raise NotImplementedError("block_out_channels must be multiples of 64")
+        if cfg["cross_attention_dim"] % 64 if isinstance(cfg["cross_attention_dim"], int) else True:
+            raise NotImplementedError("cross_attention_dim must be an int multiple of 64")
+        self.num_upsamplers = n - 1
+        self.sample_size = cfg["sample_size"]
+        self._device = torch.device("cpu")
+        self._dtype = torch.float32
+        self._sd: Optional[Dict[str, torch.Tensor]] = None   # fp32 CPU master copy (diffusers key names)
+        self._w: Optional[Dict[str, Any]] = None             # packed device weights
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._cache: Dict[str, Tuple[Tuple, Any]] = {}
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def modules(self):
+        return iter(())
+
+    def parameters(self):
+        return iter((self._sd or {}).values())
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def set_use_memory_efficient_attention_xformers(self, valid: bool = True, attention_op=None):
+        """No-op: the fused HIP attention kernel is always used (ref stage2_batchtest_inpaint_model.py:133)."""
+
+    enable_xformers_memory_efficient_attention = set_use_memory_efficient_attention_xformers
+
+    def to(self, *args, **kwargs):
+        device, dtype = kwargs.get("device"), kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif a is not None:
+                device = torch.device(a)
+        if dtype is not None:
+            self._dtype = dtype  # I/O dtype only; arithmetic is bf16 x bf16 -> fp32 on MFMA
+        if device is not None and torch.device(device) != self._device:
+            self._device = torch.device(device)
+            if self._device.type == "cuda" and self._device.index is None:
+                self._device = torch.device("cuda", torch.cuda.current_device())
+            self._w = None
+            self._bufs.clear()
+            self._cache.clear()
+        return self
+
+    def half(self):
+        return self.to(torch.float16)
+
+    # ------------------------------------------------------------------ weights
+    def expected_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        return dict(_param_shapes(self))
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        if self._sd is None:
+            raise RuntimeError("no weights loaded")
+        return dict(self._sd)
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        exp = self.expected_shapes()
+        missing = [k for k in exp if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in exp]
+        bad = [f"{k}: {tuple(state_dict[k].shape)} vs {exp[k]}" for k in exp
+               if k in state_dict and tuple(state_dict[k].shape) != tuple(exp[k])]
+        if bad or (strict and (missing or unexpected)):
+            raise RuntimeError("Error(s) in loading state_dict for Stage2_InapintUNet2DConditionModel:\n"
+                               f"  Missing key(s): {missing[:8]}{'...' if len(missing) > 8 else ''}\n"
+                               f"  Unexpected key(s): {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}\n"
+                               f"  size mismatch: {bad[:8]}")
+        base = self._sd or {}
+        self._sd = {k: (state_dict[k].detach().to("cpu", torch.float32) if k in state_dict else base[k]) for k in exp}
+        self._w = None
+        self._cache.clear()
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def init_weights(self, seed: int = 0):
+        """PyTorch-default init (what from_pretrained leaves in re-initialised tensors)."""
+        g = torch.Generator().manual_seed(seed)
+        exp = self.expected_shapes()
+        sd = {}
+        for k, shp in exp.items():
+            wk = k[: k.rfind(".") + 1] + "weight"
+            if len(exp[wk]) == 1:
+                sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+            else:
+                bound = 1.0 / math.sqrt(math.prod(exp[wk][1:]))
+                sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        self._sd = sd
+        self._w = None
+        return self
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = dict(config.__dict__ if isinstance(config, SimpleNamespace) else config)
+        cfg = {k: v for k, v in cfg.items() if k in _DEFAULT_CONFIG or k.startswith("_")}
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None, torch_dtype=None,
+                        low_cpu_mem_usage: bool = False, ignore_mismatched_sizes: bool = False, **kwargs):
+        """Reads ``{path}/{subfolder}/config.json`` + ``diffusion_pytorch_model.{safetensors,bin}``; ctor kwargs
+        override the config; with ``ignore_mismatched_sizes`` shape-mismatched tensors (conv_in when
+        in_channels 4 -> 9) keep their fresh init, as diffusers does (ref stage2_batchtest_inpaint_model.py:125-128).
+        A path without config.json falls back to the SD-2.1-base UNet config."""
+        root = Path(str(pretrained_model_name_or_path))
+        d = root / subfolder if subfolder else root
+        cfg = dict(SD21_BASE_UNET_CONFIG)
+        cj = d / "config.json"
+        if cj.exists():
+            cfg = {k: v for k, v in json.loads(cj.read_text()).items() if k in _DEFAULT_CONFIG or k.startswith("_")}
+        cfg.update(kwargs)
+        model = cls(**cfg)
+        model.init_weights(seed=0)
+        sd = None
+        if (d / "diffusion_pytorch_model.safetensors").exists():
+            from safetensors.torch import load_file
+            sd = load_file(str(d / "diffusion_pytorch_model.safetensors"))
+        elif (d / "diffusion_pytorch_model.bin").exists():
+            sd = torch.load(str(d / "diffusion_pytorch_model.bin"), map_location="cpu")
+        if sd is not None:
+            exp = model.expected_shapes()
+            mism = [k for k in sd if k in exp and tuple(sd[k].shape) != tuple(exp[k])]
+            if mism and not ignore_mismatched_sizes:
+                raise ValueError(f"size mismatch for {mism}; pass ignore_mismatched_sizes=True")
+            model.load_state_dict({k: v for k, v in sd.items() if k in exp and k not in mism}, strict=False)
+        if torch_dtype is not None:
+            model.to(torch_dtype)
+        return model
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self):
+        if self._sd is None:
+            raise RuntimeError("weights not loaded: call load_state_dict / from_pretrained first")
+        if self._device.type != "cuda" and not _emu():
+            raise RuntimeError("Stage2_InapintUNet2DConditionModel runs on the MI355X only: call .to('cuda') "
+                               "(there is no CPU implementation)")
+        sd, dev = self._sd, self._device
+        w: Dict[str, Any] = {}
+
+        def f32(k):
+            return sd[k].to(dev, torch.float32).contiguous()
+
+        def lin(p, bias=True):
+            return ops.pack_linear(sd[p + "weight"], sd[p + "bias"] if bias and p + "bias" in sd else None, dev)
+
+        def conv(p):
+            return ops.pack_conv3x3(sd[p + "weight"], sd[p + "bias"], dev)
+
+        def small(p):
+            return sd[p + "weight"].to(BF16).to(dev).contiguous(), f32(p + "bias")
+
+        w["conv_in"] = conv("conv_in.")
+        w["time1"], w["time2"] = small("time_embedding.linear_1."), small("time_embedding.linear_2.")
+        if self.config.class_embed_type == "projection":
+            w["class1"], w["class2"] = small("class_embedding.linear_1."), small("class_embedding.linear_2.")
+        tw, tb, off = [], [], 0
+        for p, cin, cout, _ in _resnets(self):
+            r: Dict[str, Any] = dict(cin=cin, cout=cout, toff=off)
+            r["n1"] = (f32(p + "norm1.weight"), f32(p + "norm1.bias"))
+            r["n2"] = (f32(p + "norm2.weight"), f32(p + "norm2.bias"))
+            r["conv1"], r["conv2"] = conv(p + "conv1."), conv(p + "conv2.")
+            if cin != cout:
+                r["short"] = lin(p + "conv_shortcut.")
+            tw.append(sd[p + "time_emb_proj.weight"])
+            tb.append(sd[p + "time_emb_proj.bias"])
+            off += cout
+            w[p] = r
+        w["temb_w"] = torch.cat(tw, 0).to(BF16).to(dev).contiguous()   # [sum Cout, 1280]: one launch for 22 projections
+        w["temb_b"] = torch.cat(tb, 0).to(dev, torch.float32).contiguous()
+        w["temb_n"] = off
+        for p, c, h in _transformers(self):
+            a: Dict[str, Any] = dict(c=c, heads=h)
+            a["norm"] = (f32(p + "norm.weight"), f32(p + "norm.bias"))
+            a["proj_in"], a["proj_out"] = lin(p + "proj_in."), lin(p + "proj_out.")
+            b = p + "transformer_blocks.0."
+            for i in (1, 2, 3):
+                a[f"ln{i}"] = (f32(b + f"norm{i}.weight"), f32(b + f"norm{i}.bias"))
+            a["qkv"] = ops.pack_linear(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"],
+                                                  sd[b + "attn1.to_v.weight"]], 0), None, dev)
+            a["o1"] = lin(b + "attn1.to_out.0.")
+            a["q2"] = ops.pack_linear(sd[b + "attn2.to_q.weight"], None, dev)
+            a["kv2"] = ops.pack_linear(torch.cat([sd[b + "attn2.to_k.weight"], sd[b + "attn2.to_v.weight"]], 0), None, dev)
+            a["o2"] = lin(b + "attn2.to_out.0.")
+            a["ff1"] = ops.pack_geglu(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"], dev)
+            a["ff2"] = lin(b + "ff.net.2.")
+            w[p] = a
+        for i in range(len(self._boc) - 1):
+            w[f"down_blocks.{i}.downsamplers.0.conv."] = conv(f"down_blocks.{i}.downsamplers.0.conv.")
+            w[f"up_blocks.{i}.upsamplers.0.conv."] = conv(f"up_blocks.{i}.upsamplers.0.conv.")
+        w["norm_out"] = (f32("conv_norm_out.weight"), f32("conv_norm_out.bias"))
+        w["conv_out"] = conv("conv_out.")
+        self._w = w
+
+    # ------------------------------------------------------------------ scratch / caches
+    def _buf(self, name: str, shape, dtype=BF16, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self._device)
+            self._bufs[key] = t
+        return t
+
+    def _cached(self, slot: str, src: torch.Tensor, extra=()):
+        key = (src.data_ptr(), src._version, tuple(src.shape), src.dtype, *extra)
+        hit = self._cache.get(slot)
+        return hit[1] if hit is not None and hit[0] == key else None
+
+    def _store(self, slot: str, src: torch.Tensor, value, extra=()):
+        self._cache[slot] = ((src.data_ptr(), src._version, tuple(src.shape), src.dtype, *extra), value)
+        return value
+
+    def invalidate_caches(self):
+        self._cache.clear()
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
+                encoder_hidden_states: torch.Tensor, class_labels: Optional[torch.Tensor] = None,
+                timestep_cond: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+                added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
+                down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
+                mid_block_additional_residual: Optional[torch.Tensor] = None,
+                encoder_attention_mask: Optional[torch.Tensor] = None, my_pose_cond: Optional[torch.Tensor] = None,
+                return_dict: bool = True, _step_dev: Optional[torch.Tensor] = None):
+        for name, v in (("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
+                        ("added_cond_kwargs", added_cond_kwargs),
+                        ("down_block_additional_residuals", down_block_additional_residuals),
+                        ("mid_block_additional_residual", mid_block_additional_residual),
+                        ("encoder_attention_mask", encoder_attention_mask)):
+            if v is not None:
+                raise NotImplementedError(f"{name} is not part of the stage-2 path")
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs (LoRA scale etc.) is not part of the stage-2 path")
+        if self.config.class_embed_type is not None and class_labels is None:
+            raise ValueError("class_labels should be provided when num_class_embeds > 0")
+        if my_pose_cond is None:
+            raise ValueError("my_pose_cond is required (ref stage2_inpaint_unet_2d_condition.py:742)")
+        if sample.dim() != 4 or sample.shape[1] != self.config.in_channels:
+            raise ValueError(f"sample must be [B,{self.config.in_channels},h,w], got {tuple(sample.shape)}")
+        B, _, h, w = sample.shape
+        if any(s % (2 ** self.num_upsamplers) for s in (h, w)):
+            raise NotImplementedError("latent height/width must be multiples of 2**num_upsamplers (ref :625-633)")
+        if self._w is None:
+            self._pack()
+        if sample.device != self._device:
+            raise RuntimeError(f"sample on {sample.device}, model on {self._device}")
+        x_in = ops.nchw_to_nhwc_bf16(sample, self._buf("x_in", (B, h, w, self._w["conv_in"].cin)),
+                                     cpad=self._w["conv_in"].cin)
+        eps = self._forward_nhwc(x_in, B, h, w, timestep, encoder_hidden_states, class_labels, my_pose_cond, _step_dev)
+        out = eps if sample.dtype == torch.float32 else eps.to(sample.dtype)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    # -- the schedule proper; x_in is NHWC bf16 [B,h,w,cin_pad]; returns fp32 NCHW eps (a reused buffer)
+    def _forward_nhwc(self, x_in, B, h, w, timestep, ehs, class_labels, pose, step_dev=None) -> torch.Tensor:
+        W, cfg, dev = self._w, self.config, self._device
+        boc, G, eps = self._boc, cfg.norm_num_groups, cfg.norm_eps
+        nlev = len(boc)
+        temb_dim = boc[0] * 4
+
+        # ---- 1. time / class embedding (ref :661-708)
+        if torch.is_tensor(timestep):
+            t_dev = timestep.reshape(-1)[:1] if step_dev is None else timestep.reshape(-1)
+            if t_dev.dtype != torch.int64 or t_dev.device != dev:
+                t_dev = t_dev.to(dev, torch.int64)
+        else:
+            t_dev = torch.tensor([int(timestep)], dtype=torch.int64, device=dev)
+        t_emb = ops.timestep_embedding(t_dev, step_dev, self._buf("t_emb", (B, boc[0]), torch.float32),
+                                       cfg.flip_sin_to_cos, float(cfg.freq_shift))
+        cls_emb = None
+        if cfg.class_embed_type == "projection":
+            cls_emb = self._cached("cls", class_labels)
+            if cls_emb is None:
+                cl = class_labels.reshape(B, -1).to(dev, torch.float32).contiguous()
+                c1 = ops.small_linear(cl, W["class1"][0], W["class1"][1], self._buf("cls1", (B, temb_dim), torch.float32),
+                                      act_out=True)
+                cls_emb = ops.small_linear(c1, W["class2"][0], W["class2"][1],
+                                           self._buf("cls2", (B, temb_dim), torch.float32))
+                self._store("cls", class_labels, cls_emb)
+        e1 = ops.small_linear(t_emb, W["time1"][0], W["time1"][1], self._buf("e1", (B, temb_dim), torch.float32), act_out=True)
+        emb = ops.small_linear(e1, W["time2"][0], W["time2"][1], self._buf("emb", (B, temb_dim), torch.float32), add=cls_emb)
+        # every ResnetBlock2D.time_emb_proj(silu(emb)) in one launch
+        temb = ops.small_linear(emb, W["temb_w"], W["temb_b"], self._buf("temb", (B, W["temb_n"]), torch.float32), act_in=True)
+
+        # ---- step-invariant conditioning (Appendix C-5), cached on tensor identity
+        pose_nhwc = self._cached("pose", pose)
+        if pose_nhwc is None:
+            if pose.shape[0] not in (1, B) or tuple(pose.shape[1:]) != (boc[0], h, w):
+                raise ValueError(f"my_pose_cond must be [1|{B},{boc[0]},{h},{w}], got {tuple(pose.shape)}")
+            pose_nhwc = self._store("pose", pose, ops.nchw_to_nhwc_bf16(
+                pose.to(dev), self._buf("pose", (pose.shape[0], h, w, boc[0]))))
+        kv = self._cached("kv", ehs)
+        L = ehs.shape[1]
+        if kv is None:
+            if ehs.shape[0] != B or ehs.shape[2] != cfg.cross_attention_dim:
+                raise ValueError(f"encoder_hidden_states must be [{B},L,{cfg.cross_attention_dim}]")
+            ctx = ops.f32_to_bf16(ehs.reshape(B * L, -1).to(dev, torch.float32).contiguous(),
+                                  self._buf("ctx", (B * L, cfg.cross_attention_dim)))
+            Lp = (L + 7) // 8 * 8
+            kv = {}
+            for p, c, _ in _transformers(self):
+                kbuf = self._buf(("k2", p), (B * L, c))
+                vtbuf = self._buf(("vt2", p), (B, c, Lp), zero=True)
+                ops.gemm(ctx, W[p]["kv2"], kbuf, rows_per_batch=L, epilogue=ops.EPI_SPLIT_VT, out2=vtbuf, vt_col0=c)
+                kv[p] = (kbuf, vtbuf)
+            self._store("kv", ehs, kv)
+
+        def resnet(p, x1, x2, HW_, hh, ww, name):
+            r = W[p]
+            cin, cout, M = r["cin"], r["cout"], B * HW_
+            ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32)
+            n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
+            cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
+            tv = temb[:, r["toff"]: r["toff"] + cout]
+            h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_)
+            n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
+            if "short" in r:
+                res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
+            else:
+                res = x1
+            return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M)
+
+        def transformer(p, x, HW_, name):
+            a = W[p]
+            c, H, M = a["c"], a["heads"], B * HW_
+            ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32)
+            n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
+            t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)))
+            # self-attention
+            l1 = ops.layernorm(t0, a["ln1"][0], a["ln1"][1], 1e-5, self._buf("ln", (M, c)))
+            qk = self._buf("qk", (M, 2 * c))
+            vt = self._buf("vt", (B, c, (HW_ + 7) // 8 * 8), zero=True)
+            ops.gemm(l1, a["qkv"], qk, rows_per_batch=HW_, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * c)
+            at = ops.flash_attn(qk[:, :c], qk[:, c:], vt, self._buf("at", (M, c)), B, H, HW_, HW_)
+            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M)
+            # cross-attention over the 258 context tokens
+            l2 = ops.layernorm(t1, a["ln2"][0], a["ln2"][1], 1e-5, self._buf("ln", (M, c)))
+            q2 = ops.gemm(l2, a["q2"], self._buf("q2", (M, c)))
+            k2, vt2 = kv[p]
+            at2 = ops.flash_attn(q2, k2, vt2, self._buf("at", (M, c)), B, H, HW_, L)
+            t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M)
+            # GEGLU feed-forward
+            l3 = ops.layernorm(t2, a["ln3"][0], a["ln3"][1], 1e-5, self._buf("ln", (M, c)))
+            ff = ops.gemm(l3, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU)
+            t3 = ops.gemm(ff, a["ff2"], self._buf("t1", (M, c)), residual=t2, res_mod=M)
+            return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M)
+
+        # ---- 2. conv_in + pose (ref :742)
+        HW = h * w
+        x = ops.gemm(x_in, W["conv_in"], self._buf("skip0", (B * HW, boc[0])), conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w),
+                     residual=pose_nhwc.view(-1, boc[0]), res_mod=pose_nhwc.shape[0] * HW)
+        # ---- 3. down (ref :746-761)
+        skips: List[Tuple[torch.Tensor, int, int]] = [(x, h, w)]
+        hh, ww = h, w
+        L_ = self._layers[0]
+        for i, typ in enumerate(cfg.down_block_types):
+            for j in range(L_):
+                nm = f"d{i}.{j}"
+                if typ == "CrossAttnDownBlock2D":
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r")
+                    x = transformer(f"down_blocks.{i}.attentions.{j}.", x, hh * ww, nm)
+                else:
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm)
+                skips.append((x, hh, ww))
+            if i != nlev - 1:
+                ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+                x = ops.gemm(x.view(B, hh, ww, boc[i]), W[f"down_blocks.{i}.downsamplers.0.conv."],
+                             self._buf(f"ds{i}", (B * ho * wo, boc[i])),
+                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, stride=2))
+                hh, ww = ho, wo
+                skips.append((x, hh, ww))
+        # ---- 4. mid (ref :775-783)
+        x = resnet("mid_block.resnets.0.", x, None, hh * ww, hh, ww, "r")
+        x = transformer("mid_block.attentions.0.", x, hh * ww, "r2")
+        x = resnet("mid_block.resnets.1.", x, None, hh * ww, hh, ww, "r")
+        # ---- 5. up (ref :789-814)
+        rev = list(reversed(boc))
+        for i, typ in enumerate(cfg.up_block_types):
+            for j in range(L_ + 1):
+                sk, sh, sw = skips.pop()
+                assert (sh, sw) == (hh, ww)
+                x = resnet(f"up_blocks.{i}.resnets.{j}.", x, sk, hh * ww, hh, ww, "r" if (j + i) % 2 else "rb")
+                if typ == "CrossAttnUpBlock2D":
+                    x = transformer(f"up_blocks.{i}.attentions.{j}.", x, hh * ww, "u" if j % 2 else "ub")
+            if i != nlev - 1:
+                x = ops.gemm(x.view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
+                             self._buf("us", (B * 4 * hh * ww, rev[i])),
+                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=2 * hh, Wo=2 * ww, upsample=1))
+                hh, ww = 2 * hh, 2 * ww
+        # ---- 6. post-process (ref :817-820)
+        ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32)
+        n = ops.groupnorm(x, None, B, HW, G, eps, W["norm_out"][0], W["norm_out"][1], True, self._buf("gn", (B * HW, boc[0])), ws)
+        out = self._buf("eps", (B, cfg.out_channels, h, w), torch.float32)
+        ops.gemm(n, W["conv_out"], out, conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w), rows_per_batch=HW,
+                 epilogue=ops.EPI_NCHW_F32)
+        return out
+
+
+def _emu() -> bool:
+    from . import _lib
+    return _lib.is_emulator()
+
+
+# ---------------------------------------------------------------------- topology walkers
+def _resnets(m: Stage2_InapintUNet2DConditionModel) -> Iterator[Tuple[str, int, int, int]]:
+    """(prefix, cin, cout, level) of every ResnetBlock2D, following ref ctor :314-431."""
+    boc, L = m._boc, m._layers[0]
+    out = boc[0]
+    for i in range(len(boc)):
+        cin, out = out, boc[i]
+        for j in range(L):
+            yield f"down_blocks.{i}.resnets.{j}.", (cin if j == 0 else out), out, i
+    yield "mid_block.resnets.0.", boc[-1], boc[-1], len(boc) - 1
+    yield "mid_block.resnets.1.", boc[-1], boc[-1], len(boc) - 1
+    rev = list(reversed(boc))
+    out = rev[0]
+    for i in range(len(boc)):
+        prev, out = out, rev[i]
+        inc = rev[min(i + 1, len(boc) - 1)]
+        for j in range(L + 1):
+            skip = inc if j == L else out
+            rin = prev if j == 0 else out
+            yield f"up_blocks.{i}.resnets.{j}.", rin + skip, out, len(boc) - 1 - i
+
+
+def _transformers(m: Stage2_InapintUNet2DConditionModel) -> Iterator[Tuple[str, int, int]]:
+    boc, L = m._boc, m._layers[0]
+    for i, typ in enumerate(m.config.down_block_types):
+        if typ == "CrossAttnDownBlock2D":
+            for j in range(L):
+                yield f"down_blocks.{i}.attentions.{j}.", boc[i], m._heads[i]
+        elif typ != "DownBlock2D":
+            raise NotImplementedError(typ)
+    yield "mid_block.attentions.0.", boc[-1], m._heads[-1]
+    rev, rh = list(reversed(boc)), list(reversed(m._heads))
+    for i, typ in enumerate(m.config.up_block_types):
+        if typ == "CrossAttnUpBlock2D":
+            for j in range(L + 1):
+                yield f"up_blocks.{i}.attentions.{j}.", rev[i], rh[i]
+        elif typ != "UpBlock2D":
+            raise NotImplementedError(typ)
+
+
+def _param_shapes(m: Stage2_InapintUNet2DConditionModel) -> Iterator[Tuple[str, Tuple[int, ...]]]:
+    """diffusers state-dict names and shapes."""
+    cfg, boc = m.config, m._boc
+    temb, ctx = boc[0] * 4, cfg.cross_attention_dim
+    yield "conv_in.weight", (boc[0], cfg.in_channels, 3, 3)
+    yield "conv_in.bias", (boc[0],)
+    for nm, din in (("time_embedding", boc[0]),) + ((("class_embedding", cfg.projection_class_embeddings_input_dim),)
+                                                    if cfg.class_embed_type == "projection" else ()):
+        yield f"{nm}.linear_1.weight", (temb, din)
+        yield f"{nm}.linear_1.bias", (temb,)
+        yield f"{nm}.linear_2.weight", (temb, temb)
+        yield f"{nm}.linear_2.bias", (temb,)
+    for p, cin, cout, _ in _resnets(m):
+        yield p + "norm1.weight", (cin,)
+        yield p + "norm1.bias", (cin,)
+        yield p + "conv1.weight", (cout, cin, 3, 3)
+        yield p + "conv1.bias", (cout,)
+        yield p + "time_emb_proj.weight", (cout, temb)
+        yield p + "time_emb_proj.bias", (cout,)
+        yield p + "norm2.weight", (cout,)
+        yield p + "norm2.bias", (cout,)
+        yield p + "conv2.weight", (cout, cout, 3, 3)
+        yield p + "conv2.bias", (cout,)
+        if cin != cout:
+            yield p + "conv_shortcut.weight", (cout, cin, 1, 1)
+            yield p + "conv_shortcut.bias", (cout,)
+    lin = (lambda o, i: (o, i)) if cfg.use_linear_projection else (lambda o, i: (o, i, 1, 1))
+    for p, c, _ in _transformers(m):
+        yield p + "norm.weight", (c,)
+        yield p + "norm.bias", (c,)
+        yield p + "proj_in.weight", lin(c, c)
+        yield p + "proj_in.bias", (c,)
+        b = p + "transformer_blocks.0."
+        for i, kd in ((1, c), (2, ctx)):
+            yield b + f"norm{i}.weight", (c,)
+            yield b + f"norm{i}.bias", (c,)
+            yield b + f"attn{i}.to_q.weight", (c, c)
+            yield b + f"attn{i}.to_k.weight", (c, kd)
+            yield b + f"attn{i}.to_v.weight", (c, kd)
+            yield b + f"attn{i}.to_out.0.weight", (c, c)
+            yield b + f"attn{i}.to_out.0.bias", (c,)
+        yield b + "norm3.weight", (c,)
+        yield b + "norm3.bias", (c,)
+        yield b + "ff.net.0.proj.weight", (8 * c, c)
+        yield b + "ff.net.0.proj.bias", (8 * c,)
+        yield b + "ff.net.2.weight", (c, 4 * c)
+        yield b + "ff.net.2.bias", (c,)
+        yield p + "proj_out.weight", lin(c, c)
+        yield p + "proj_out.bias", (c,)
+    for i in range(len(boc) - 1):
+        yield f"down_blocks.{i}.downsamplers.0.conv.weight", (boc[i], boc[i], 3, 3)
+        yield f"down_blocks.{i}.downsamplers.0.conv.bias", (boc[i],)
+    rev = list(reversed(boc))
+    for i in range(len(boc) - 1):
+        yield f"up_blocks.{i}.upsamplers.0.conv.weight", (rev[i], rev[i], 3, 3)
+        yield f"up_blocks.{i}.upsamplers.0.conv.bias", (rev[i],)
+    yield "conv_norm_out.weight", (boc[0],)
+    yield "conv_norm_out.bias", (boc[0],)
+    yield "conv_out.weight", (cfg.out_channels, boc[0], 3, 3)
+    yield "conv_out.bias", (cfg.out_channels,)
+
+
+# friendlier alias
+Stage2InpaintUNet = Stage2_InapintUNet2DConditionModel

@@ -1,0 +1,114 @@
+"""UNet forward parity: pcdms_amd.Stage2_InapintUNet2DConditionModel (HIP) vs the fp32 CPU oracle.
+
+Tolerance (stated, SURVEY.md §7 iv): the HIP path computes bf16 x bf16 -> fp32 with bf16 activations
+between kernels; against the fp32 oracle on identical weights/inputs we require
+rel-L2(eps) <= 2.5e-2 and max-abs <= 6% of max|eps| for one forward (61 norm layers deep).
+"""
+from __future__ import annotations
+
+import pytest
+import torch
+
+from oracle.unet import UNetConfig, param_count, param_shapes, synth_state_dict, unet_forward
+from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
+
+REL_L2_TOL = 2.5e-2
+MAX_ABS_TOL = 6e-2
+
+
+def _kwargs(cfg: UNetConfig):
+    return dict(in_channels=cfg.in_channels, block_out_channels=cfg.block_out_channels,
+                attention_head_dim=cfg.attention_head_dim, cross_attention_dim=cfg.cross_attention_dim,
+                use_linear_projection=True, class_embed_type=cfg.class_embed_type,
+                projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim,
+                sample_size=cfg.sample_size)
+
+
+def _inputs(cfg, B, h, w, L, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.randn(B, 9, h, w, generator=g)
+    ehs = torch.randn(B, L, cfg.cross_attention_dim, generator=g)
+    ehs[: B // 2] = 0  # uncond rows, as the pipeline builds them (ref stage2_inpaint_pipeline.py:455-458)
+    cl = torch.randn(B, 1, cfg.projection_class_embeddings_input_dim, generator=g) * 0.4
+    pose = torch.randn(1, cfg.block_out_channels[0], h, w, generator=g) * 0.1
+    return sample, ehs, cl, pose
+
+
+def _check(out, ref):
+    out, ref = out.float().cpu(), ref.float()
+    assert torch.isfinite(out).all()
+    rel = ((out - ref).norm() / ref.norm()).item()
+    mx = ((out - ref).abs().max() / ref.abs().max()).item()
+    assert rel <= REL_L2_TOL and mx <= MAX_ABS_TOL, f"rel-L2 {rel:.4f}, max-abs/scale {mx:.4f}"
+    return rel, mx
+
+
+def test_state_dict_contract():
+    """Key names / shapes / parameter count agree between product and oracle (SURVEY.md §8c a)."""
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(UNetConfig()))
+    exp = m.expected_shapes()
+    ref = dict(param_shapes(UNetConfig()))
+    assert exp == {k: tuple(v) for k, v in ref.items()}
+    assert sum(torch.Size(s).numel() for s in exp.values()) == 868_876_804 == param_count(UNetConfig())
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"conv_in.weight": torch.zeros(320, 9, 3, 3)})
+    with pytest.raises(NotImplementedError):
+        Stage2_InapintUNet2DConditionModel(addition_embed_type="text")
+
+
+def test_forward_errors_and_cpu_refusal():
+    cfg = UNetConfig.tiny()
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(synth_state_dict(cfg, 0))
+    s, e, c, p = _inputs(cfg, 2, 8, 8, 5)
+    with pytest.raises(ValueError):
+        m(s, 10, e, class_labels=None, my_pose_cond=p)
+    with pytest.raises(NotImplementedError):
+        m(s, 10, e, class_labels=c, my_pose_cond=p, attention_mask=torch.ones(2, 5))
+    from pcdms_amd import _lib
+    _lib._lib = None  # product library (or none at all): CPU tensors must be refused, never silently computed
+    try:
+        with pytest.raises(RuntimeError):
+            m(s, 10, e, class_labels=c, my_pose_cond=p)
+    finally:
+        _lib._lib = None
+
+
+def _run(backend, cfg, B, h, w, L, random_affine=True, t=981):
+    sd = synth_state_dict(cfg, seed=0, random_affine=random_affine)
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(backend.device)
+    s, e, c, p = _inputs(cfg, B, h, w, L)
+    dev = backend.device
+    out = m(s.to(dev), torch.tensor(t, device=dev), e.to(dev), class_labels=c.to(dev), my_pose_cond=p.to(dev),
+            return_dict=False)[0]
+    backend.sync()
+    ref = unet_forward(sd, cfg, s, torch.tensor(t), e, c, p)
+    return m, out, ref, (s, e, c, p)
+
+
+def test_unet_tiny(backend):
+    cfg = UNetConfig.tiny()
+    B, h, w, L = (2, 8, 8, 5) if backend.is_emu else (4, 16, 24, 10)
+    m, out, ref, (s, e, c, p) = _run(backend, cfg, B, h, w, L)
+    _check(out, ref)
+    # second call with the same conditioning tensors exercises the step-invariant caches
+    dev = backend.device
+    s2 = torch.randn(s.shape, generator=torch.Generator().manual_seed(5))
+    ehs_d, cl_d, pose_d = e.to(dev), c.to(dev), p.to(dev)
+    o1 = m(s2.to(dev), 500, ehs_d, class_labels=cl_d, my_pose_cond=pose_d).sample.clone()
+    o2 = m(s2.to(dev), 500, ehs_d, class_labels=cl_d, my_pose_cond=pose_d).sample
+    backend.sync()
+    assert torch.equal(o1, o2)
+    sd = m.state_dict()
+    _check(o2, unet_forward(sd, cfg, s2, 500, e, c, p))
+
+
+@pytest.mark.gpu
+def test_unet_full_size_config1(gpu_backend):
+    """Full 868.9 M-parameter topology at config 1's latent 32x64 (256x256 pair), UNet batch 2."""
+    cfg = UNetConfig()
+    m, out, ref, _ = _run(gpu_backend, cfg, 2, 32, 64, 258, random_affine=False)
+    rel, mx = _check(out, ref)
+    print(f"full-size forward: rel-L2 {rel:.4f} max/scale {mx:.4f}")
