@@ -1,0 +1,249 @@
+"""Stage-2 pose-conditioned inpainting sampler on the MI355X.
+
+Mirrors ``Stage2_InpaintDiffusionPipeline.__call__``
+(/root/reference/src/pipelines/stage2_inpaint_pipeline.py:389-541): same keyword arguments, same
+conditioning assembly (:430-466), same loop body (:496-519).  Two execution modes over the same
+kernels:
+
+* ``mode="reference"`` -- literally the reference's loop: ``cat`` inputs, ``self.unet(...)``,
+  CFG combine, ``self.scheduler.step(...)`` with any scheduler object (UniPC / DDIM / DDPM).
+* ``mode="fused"`` (default when the scheduler is DDIM/DDPM-like, i.e. one linear update per step)
+  -- per step: ``pcdm_assemble_input`` -> UNet schedule -> ``pcdm_cfg_step`` (CFG + scheduler update
+  with device-side coefficient table) -> ``pcdm_advance_step``; the step is captured once in a
+  hipGraph and replayed ``num_inference_steps`` times (the step index lives in device memory), which
+  removes ~700 host launches per step from the critical path.
+
+VAE encode/decode are outside the hot path: pass ``masked_latents``
+(= vae.encode(vae_image).sample * scaling_factor, ref :443-444) and read ``output.latents``.
+"""
+from __future__ import annotations
+
+import inspect
+from dataclasses import dataclass
+from typing import Any, Callable, List, Optional, Union
+
+import torch
+
+from . import ops
+from .schedulers import DDIMScheduler, DDPMScheduler
+from .unet import Stage2_InapintUNet2DConditionModel
+
+
+@dataclass
+class Stage2_InpaintDiffusionPipelineOutput:
+    images: Any
+    nsfw_content_detected: Optional[List[bool]] = None
+    latents: Optional[torch.Tensor] = None
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """ref :52-63.  Inactive in the reference driver (guidance_rescale=0.0,
+    stage2_batchtest_inpaint_model.py:191); provided for API completeness (tiny per-sample statistics)."""
+    raise NotImplementedError("guidance_rescale > 0 is not on the stage-2 hot path (driver passes 0.0)")
+
+
+class Stage2_InpaintDiffusionPipeline:
+    def __init__(self, unet: Stage2_InapintUNet2DConditionModel, scheduler, vae=None):
+        self.unet = unet
+        self.scheduler = scheduler
+        self.vae = vae
+        self.vae_scale_factor = 8
+        self._graph = None
+        self._graph_key = None
+        self._st = {}
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    _execution_device = device
+
+    def to(self, device):
+        self.unet.to(device)
+        return self
+
+    def enable_xformers_memory_efficient_attention(self, attention_op=None):
+        self.unet.set_use_memory_efficient_attention_xformers(True, attention_op)
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """ref :307-322."""
+        params = set(inspect.signature(self.scheduler.step).parameters.keys())
+        kw = {}
+        if "eta" in params:
+            kw["eta"] = eta
+        if "generator" in params:
+            kw["generator"] = generator
+        return kw
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        """ref :371-387."""
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}.")
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else device
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device)
+        else:
+            latents = latents.to(device)
+        return latents.to(dtype) * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None,
+                 num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1,
+                 cross_attention_kwargs=None, guidance_rescale: float = 0.0,
+                 vae_image: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                 s_img_proj_f: Optional[torch.Tensor] = None, st_pose_f: Optional[torch.Tensor] = None,
+                 pred_t_img_embed: Optional[torch.Tensor] = None,
+                 # extensions
+                 masked_latents: Optional[torch.Tensor] = None, mode: Optional[str] = None, use_graph: bool = True):
+        if prompt is not None or prompt_embeds is not None or negative_prompt is not None:
+            raise NotImplementedError("text prompts are not part of the stage-2 path (dead code in the reference, :245-291)")
+        device = self.device
+        if height % 8 or width % 8:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if guidance_rescale > 0.0:
+            rescale_noise_cfg(None, None, guidance_rescale)
+        bs, num, _ = s_img_proj_f.shape
+        N = num_images_per_prompt
+        h, w = height // 8, width // 8
+        do_cfg = guidance_scale > 1.0
+        rep = 2 if do_cfg else 1
+        f32 = dict(device=device, dtype=torch.float32)
+
+        # ---- conditioning (ref :430-466); sample index = pair*N + k, CFG layout [uncond(all); cond(all)]
+        if masked_latents is None:
+            if self.vae is None:
+                raise ValueError("pass masked_latents=... (VAE encode is outside the hot path) or construct with vae=")
+            masked_latents = self.vae.encode(vae_image.to(device)).latent_dist.sample(generator=generator)
+            masked_latents = masked_latents * self.vae.config.scaling_factor
+        masked = masked_latents.to(**f32).repeat_interleave(N, 0).repeat(rep, 1, 1, 1).contiguous() if bs > 1 \
+            else masked_latents.to(**f32).contiguous()                      # bs == 1: batch-broadcast in the kernel
+        if mask is None:
+            mask = torch.cat([torch.ones(bs, 1, h, w // 2), torch.zeros(bs, 1, h, w // 2)], dim=3)
+        mask = mask.to(**f32).repeat_interleave(N, 0).repeat(rep, 1, 1, 1).contiguous() if bs > 1 \
+            else mask.to(**f32).contiguous()
+        pose = st_pose_f.to(**f32)
+        pose_cond = pose.repeat_interleave(N, 0).repeat(rep, 1, 1, 1).contiguous() if bs > 1 else pose.contiguous()
+        feature_f = torch.cat([s_img_proj_f.to(**f32), pred_t_img_embed.to(**f32)], dim=1).repeat_interleave(N, 0)
+        prior_embed = pred_t_img_embed.to(**f32).repeat_interleave(N, 0)
+        if do_cfg:
+            feature_f = torch.cat([torch.zeros_like(feature_f), feature_f], dim=0)
+            prior_embed = torch.cat([torch.zeros_like(prior_embed), prior_embed], dim=0)
+        feature_f, prior_embed = feature_f.contiguous(), prior_embed.contiguous()
+
+        # ---- timesteps, latents (ref :472-487)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        lat = self.prepare_latents(bs * N, 4, height, width, torch.float32, device, generator, latents).contiguous()
+        extra = self.prepare_extra_step_kwargs(generator, eta)
+
+        linear = isinstance(self.scheduler, (DDIMScheduler, DDPMScheduler)) and eta == 0.0 \
+            and not isinstance(self.scheduler, DDPMScheduler)
+        mode = mode or ("fused" if linear else "reference")
+        if mode == "fused" and not linear:
+            raise ValueError("mode='fused' needs a scheduler with one deterministic linear update per step (DDIM, eta=0)")
+
+        if mode == "reference":
+            for i, t in enumerate(timesteps):
+                x = torch.cat([lat] * 2) if do_cfg else lat
+                x = self.scheduler.scale_model_input(x, t)
+                B = x.shape[0]
+                inp = torch.cat([x, mask.expand(B, -1, -1, -1), masked.expand(B, -1, -1, -1)], dim=1)
+                eps = self.unet(inp, t, class_labels=prior_embed, encoder_hidden_states=feature_f,
+                                my_pose_cond=pose_cond, return_dict=False)[0]
+                if do_cfg:
+                    g = torch.empty_like(lat)
+                    ops.cfg_step(eps.float().contiguous(), True, float(guidance_scale), None, None, None, eps_out=g)
+                    eps = g
+                lat = self.scheduler.step(eps, t, lat, **extra, return_dict=False)[0]
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, lat)
+        else:
+            lat = self._run_fused(lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg,
+                                  float(guidance_scale), eta, use_graph, callback, callback_steps)
+
+        if output_type == "latent" or self.vae is None:
+            images = lat
+        else:
+            img = self.vae.decode(lat / self.vae.config.scaling_factor, return_dict=False)[0]
+            images = (img / 2 + 0.5).clamp(0, 1)
+        if not return_dict:
+            return (images, None)
+        return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
+
+    # ------------------------------------------------------------------------------------------
+    def _step_eager(self, st):
+        unet = self.unet
+        B, h, w = st["B"], st["h"], st["w"]
+        x_in = ops.assemble_input(st["lat"], st["rep"], st["mask"], st["masked"], st["x_in"])
+        eps = unet._forward_nhwc(x_in, B, h, w, st["timesteps"], st["feature_f"], st["prior_embed"], st["pose"],
+                                 step_dev=st["step"])
+        ops.cfg_step(eps, st["rep"] == 2, st["g"], st["lat"], st["lat"], st["coef"], st["step"])
+        ops.advance_step(st["step"])
+
+    def _run_fused(self, lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, g, eta, use_graph,
+                   callback, callback_steps):
+        unet, dev = self.unet, self.device
+        if unet._w is None:
+            unet._pack()
+        n = len(timesteps)
+        N, _, h, w = lat.shape
+        rep = 2 if do_cfg else 1
+        B = rep * N
+        key = (B, h, w, n, rep, tuple(feature_f.shape), tuple(mask.shape), tuple(masked.shape), tuple(pose_cond.shape))
+        st = self._st if self._graph_key == key else {}
+        if not st:
+            st.update(B=B, h=h, w=w, rep=rep,
+                      lat=torch.empty_like(lat), mask=torch.empty_like(mask), masked=torch.empty_like(masked),
+                      pose=torch.empty_like(pose_cond), feature_f=torch.empty_like(feature_f),
+                      prior_embed=torch.empty_like(prior_embed),
+                      x_in=torch.empty(B, h, w, 64, dtype=ops.BF16, device=dev),
+                      step=torch.zeros(1, dtype=torch.int32, device=dev),
+                      timesteps=torch.empty(n, dtype=torch.int64, device=dev),
+                      coef=torch.empty(n, 4, dtype=torch.float32, device=dev))
+            self._graph = None
+        # static input slots (same addresses every call => graph replays and UNet caches stay valid)
+        st["lat"].copy_(lat)
+        changed = False
+        for name, src in (("mask", mask), ("masked", masked), ("pose", pose_cond), ("feature_f", feature_f),
+                          ("prior_embed", prior_embed)):
+            if not self._graph or not torch.equal(st[name], src):
+                st[name].copy_(src)
+                changed = True
+        if changed:
+            unet.invalidate_caches()
+        st["timesteps"].copy_(timesteps.to(dev))
+        st["coef"].copy_(self.scheduler.coefficient_table(eta, device=dev))
+        st["g"] = g
+        st["step"].zero_()
+        self._st, self._graph_key = st, key
+        simple_cb = callback is None
+        if use_graph and dev.type == "cuda" and simple_cb:
+            if self._graph is None or changed or self._st.get("g_captured") != g:
+                # warm-up step (allocates every scratch buffer, fills the step-invariant caches), then capture
+                lat0 = st["lat"].clone()
+                self._step_eager(st)
+                torch.cuda.synchronize()
+                st["lat"].copy_(lat0)
+                st["step"].zero_()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._step_eager(st)
+                st["lat"].copy_(lat0)
+                st["step"].zero_()
+                self._graph = graph
+                st["g_captured"] = g
+            for _ in range(n):
+                self._graph.replay()
+        else:
+            for i in range(n):
+                self._step_eager(st)
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, timesteps[i], st["lat"])
+        return st["lat"].clone()
