@@ -18,6 +18,7 @@ from ._lib import GemmParams
 
 EPI_STORE, EPI_GEGLU, EPI_SPLIT_VT, EPI_NCHW_F32 = 0, 1, 2, 3
 BF16 = torch.bfloat16
+LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
 
 
 def _stream(t: torch.Tensor) -> Optional[int]:
@@ -84,6 +85,7 @@ class PackedWeight:
     Npad: int
     cin: int = 0       # conv: (padded) input channels
     geglu: bool = False
+    alg_nk: int = 0    # algorithmic N*K (un-padded; GEGLU counts both halves) for FLOP accounting
 
 
 def pack_linear(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: int = 64) -> PackedWeight:
@@ -99,7 +101,7 @@ def pack_linear(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: i
         bp = torch.zeros(Npad, dtype=torch.float32)
         bp[:N] = bias.float()
         bp = bp.to(device)
-    return PackedWeight(wp.to(BF16).to(device), bp, N, K, Npad)
+    return PackedWeight(wp.to(BF16).to(device), bp, N, K, Npad, alg_nk=N * K)
 
 
 def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: int = 64) -> PackedWeight:
@@ -110,6 +112,7 @@ def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: 
     wp[..., :Cin] = w.float().permute(0, 2, 3, 1)
     pw = pack_linear(wp.reshape(N, 9 * Cp), bias, device, pad_to)
     pw.cin = Cp
+    pw.alg_nk = N * 9 * Cin
     return pw
 
 
@@ -125,7 +128,7 @@ def pack_geglu(w: torch.Tensor, bias: torch.Tensor, device) -> PackedWeight:
     bg = torch.zeros(Dp); bg[:D] = bias[D:].float()
     wp = torch.stack([wh.view(Dp // 32, 32, K), wg.view(Dp // 32, 32, K)], dim=1).reshape(2 * Dp, K)
     bp = torch.stack([bh.view(Dp // 32, 32), bg.view(Dp // 32, 32)], dim=1).reshape(2 * Dp)
-    return PackedWeight(wp.to(BF16).to(device), bp.to(device), D, K, 2 * Dp, geglu=True)
+    return PackedWeight(wp.to(BF16).to(device), bp.to(device), D, K, 2 * Dp, geglu=True, alg_nk=2 * D * K)
 
 
 # ------------------------------------------------------------------------------------ GEMM / conv
@@ -177,6 +180,13 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.out2 = _ptr(out2)
         p.ldo2 = out2.shape[-1]
     p.tile = tile
+    if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _chk(_lib.lib().pcdm_gemm(C.byref(p), _stream(a)), "pcdm_gemm")
+        e1.record()
+        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv))))
+        return out
     _chk(_lib.lib().pcdm_gemm(C.byref(p), _stream(a)), "pcdm_gemm")
     return out
 
@@ -188,9 +198,16 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
         assert t.dtype == BF16
     assert q.stride(1) == 1 and k.stride(1) == 1 and vt.is_contiguous() and out.stride(1) == 1
     scale = scale if scale is not None else 1.0 / math.sqrt(64)
+    log = LAUNCH_LOG is not None and q.is_cuda
+    if log:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib.lib().pcdm_flash_attn(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out),
                                    out.stride(0), B, H, Lq, Lk, scale, _stream(q))
     _chk(rc, "pcdm_flash_attn")
+    if log:
+        e1.record()
+        LAUNCH_LOG.append(("flash_attn_kernel", 4.0 * B * H * Lq * Lk * 64, e0, e1, (B, H, Lq, Lk)))
     return out
 
 
