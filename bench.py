@@ -165,7 +165,10 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
     torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
     fam = {}
-    for name, flops, e0, e1, _ in log:
+    tiles = {}
+    for name, flops, e0, e1, info in log:
+        if name == "gemm_kernel":
+            tiles[info[-1]] = tiles.get(info[-1], 0) + 1
         f = fam.setdefault(name, [0, 0.0, 0.0])
         f[0] += 1
         f[1] += flops
@@ -177,6 +180,7 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
            "kernel": "gemm_kernel<BM,BN,CONV> (implicit-GEMM conv3x3 + linear, all instances)",
            "launches_per_denoise_step": gk[0], "avg_launch_us": round(gk[2] / gk[0] * 1e6, 2),
            "alg_gflop_per_launch": round(gk[1] / gk[0] / 1e9, 2),
+           "tile_configs_used": {str(k): v for k, v in sorted(tiles.items())},
            "note": "HIP events around each launch of one eager denoise step (UNet batch %d, latent %dx%d)" % (2 * N, h, w)}
     if "flash_attn_kernel" in fam:
         fa = fam["flash_attn_kernel"]

@@ -74,7 +74,7 @@ typedef struct pcdm_gemm_params {
     int64_t ldo;
     void* out2;
     int64_t ldo2;
-    int32_t tile;      /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64 */
+    int32_t tile;      /* 0 = heuristic; 1..10 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
 } pcdm_gemm_params;
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 

@@ -3,18 +3,22 @@
 //   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),  fp32 accumulation on v_mfma_f32_32x32x16_bf16.
 //
 // Design (gfx950):
-//  * One workgroup = 4 waves (2x2), block tile BMxBN (128x128 or 64x64), BK = 64.  Each wave owns a
-//    (BM/2)x(BN/2) sub-tile as 32x32 MFMA fragments.  The MFMA is issued "swapped" -- D = Wfrag * Xfrag^T,
+//  * One workgroup = 8 waves (4x2; block tile 256x128 or 256x64) or 4 waves (2x2; 128x128, 64x64), BK = 64.
+//    Each wave owns a 64x64 / 64x32 / 32x32 sub-tile as 32x32 MFMA fragments.  The MFMA is issued "swapped" -- D = Wfrag * Xfrag^T,
 //    rows = output channel n, cols = pixel/token m -- so that every lane ends up with 4 CONSECUTIVE
 //    output channels of one row in each accumulator quad: the epilogue adds bias / time-embedding /
 //    residual and stores 8-byte packed bf16 without any cross-lane traffic.
-//  * A (activations, NHWC bf16) and W (packed [N][K], K contiguous) tiles are register-staged:
-//    16-byte global loads of tile t+1 are issued before the MFMAs of tile t and written to the other
-//    LDS buffer afterwards (one barrier per K-tile, cdna_hip_programming.md T14).  Register staging
-//    (rather than global_load_lds) is forced by the implicit-GEMM gather: 3x3 halo / zero padding,
-//    stride 2, nearest-x2 upsample folding and the two-source skip concat are all per-lane predicates.
-//  * LDS rows are padded 64 -> 72 bf16 (144 B): 16 distinct rows (mod 16) x 16 B cover all 64 banks,
-//    so both the ds_write_b128 staging pattern and the ds_read_b128 fragment pattern are conflict-free.
+//  * A (activations, NHWC bf16) and W (packed [N][K], K contiguous) tiles go HBM/L2 -> LDS by LDS-DMA
+//    (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip) into a ring of STAGES LDS buffers: tiles
+//    t+1 .. t+STAGES-1 are in flight while the MFMAs of tile t run; ONE raw s_barrier per K-tile preceded by
+//    a COUNTED s_waitcnt vmcnt(N) so the younger tiles' DMAs stay in flight across it (the loop is L2-latency
+//    bound otherwise: one 32 KiB tile in flight per block measured 0.58 PF/s, see profiles/).  The DMA destination is lane-linear, the
+//    per-lane SOURCE address is free -- that is where the implicit-GEMM gather lives: 3x3 halo / zero
+//    padding (lanes point at a 16-byte zero word), stride 2, nearest-x2 upsample folding and the
+//    two-source skip concat are all just per-lane source pointers.
+//  * LDS tiles are unpadded [rows][64] bf16 with the 16-byte chunk index XOR-swizzled by (row>>1)&7,
+//    applied on the DMA source address and again on the fragment reads (cdna_hip_programming.md rule 21):
+//    the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte slots of the 256-byte bank row.
 //  * Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous run of M-tiles and
 //    walks all N-tiles of an A tile back to back (cdna_hip_programming.md T1, bijective form).
 #include "pcdm_device.h"
@@ -22,7 +26,6 @@
 
 namespace {
 constexpr int BK = 64;
-constexpr int LDSK = 72;  // padded row length (bf16 elements)
 
 struct GemmArgs {
     const u16* a;
@@ -46,18 +49,36 @@ struct GemmArgs {
     u16* out2;
     int64_t ldo2;
     int tiles_m, tiles_n;
+    int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs
 };
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
-    constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per tile
+// 16 zero bytes: the LDS-DMA source of every padded / out-of-range chunk (halo, rows >= M)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+template <int N>
+__device__ __forceinline__ void wait_vm_then_barrier() {
+    // counted wait (N LDS-DMA instructions of younger tiles may stay in flight) + raw s_barrier in ONE asm
+    // statement: __syncthreads() would drain vmcnt to 0 (cdna_hip_programming.md "Pipelining across barriers")
+#ifdef PCDM_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+    constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // LDS-DMA instructions per wave per K-tile (8 rows x 128 B each)
+    constexpr int D = STAGES - 1;                      // prefetch distance (tiles in flight)
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
     PCDM_DYN_SMEM(smem);
-    u16* As = (u16*)smem;                    // [2][BM][LDSK]
-    u16* Bs = As + 2 * BM * LDSK;            // [2][BN][LDSK]
+    u16* As = (u16*)smem;                    // [STAGES][BM][64]   (unpadded, XOR-swizzled 16-byte chunks)
+    u16* Bs = As + STAGES * BM * BK;         // [STAGES][BN][64]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
 
     // XCD-aware bijective remap of the linear workgroup id
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -66,69 +87,70 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread staging coordinates
-    const int cc = t & 7;   // 16-byte chunk within the 64-wide K tile
-    const int rr = t >> 3;  // row (0..31) within each 32-row slab
-    int a_b[AR], a_y[AR], a_x[AR];  // conv: batch / out y / out x ; linear: a_b = row or -1
+    // ---- LDS-DMA staging coordinates.  Wave-instruction j of wave w fills tile rows (w*AI+j)*8 .. +7:
+    // lane i -> LDS slot i = (row i>>3, position i&7); position q of row r holds global chunk q ^ ((r>>1)&7)
+    // (swizzle on the SOURCE address, linear destination; the same XOR is applied on the fragment reads).
+    const int srow = lane >> 3, spos = lane & 7;
+    int a_b[AI], a_y[AI], a_x[AI], a_ck[AI];  // conv: batch / out y / out x ; linear: a_b = row or -1
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + rr + 32 * i;
+    for (int j = 0; j < AI; ++j) {
+        const int rl = (wave * AI + j) * 8 + srow;
+        const int m = m0 + rl;
+        a_ck[j] = (spos ^ ((rl >> 1) & 7)) * 8;
         if (m < p.M) {
             if (CONV) {
                 const int hw = p.Ho * p.Wo;
                 const int b = m / hw, rem = m - b * hw;
-                a_b[i] = b;
-                a_y[i] = rem / p.Wo;
-                a_x[i] = rem - a_y[i] * p.Wo;
+                a_b[j] = b;
+                a_y[j] = rem / p.Wo;
+                a_x[j] = rem - a_y[j] * p.Wo;
             } else {
-                a_b[i] = m;
-                a_y[i] = a_x[i] = 0;
+                a_b[j] = m;
+                a_y[j] = a_x[j] = 0;
             }
         } else {
-            a_b[i] = -1;
-            a_y[i] = a_x[i] = 0;
+            a_b[j] = -1;
+            a_y[j] = a_x[j] = 0;
         }
     }
+    const u16* b_src[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int rl = (wave * BI + j) * 8 + srow;
+        b_src[j] = p.w + (int64_t)(n0 + rl) * p.K + (spos ^ ((rl >> 1) & 7)) * 8;
+    }
     const int Hv = p.Hi << p.upsample, Wv = p.Wi << p.upsample;
+    const u16* zsrc = (const u16*)g_zero16;
 
-    u16x8 ra[AR], rb[BR];
-    auto load_tile = [&](int kt) {
+    auto issue_tile = [&](int kt, int buf) {
         const int k0 = kt * BK;
+        u16* as = As + buf * BM * BK + (wave * AI) * 8 * BK;
+        u16* bs = Bs + buf * BN * BK + (wave * BI) * 8 * BK;
         if (CONV) {
             const int tap = k0 / p.cin, c0 = k0 - tap * p.cin;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                int iy = a_y[i] * p.stride + ky - 1, ix = a_x[i] * p.stride + kx - 1;
-                const bool ok = a_b[i] >= 0 && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            for (int j = 0; j < AI; ++j) {
+                int iy = a_y[j] * p.stride + ky - 1, ix = a_x[j] * p.stride + kx - 1;
+                const bool ok = a_b[j] >= 0 && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
                 iy >>= p.upsample;
                 ix >>= p.upsample;
-                u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = *(const u16x8*)(p.a + (((int64_t)a_b[i] * p.Hi + iy) * p.Wi + ix) * p.cin + c0 + cc * 8);
-                ra[i] = v;
+                const u16* src = ok ? p.a + (((int64_t)a_b[j] * p.Hi + iy) * p.Wi + ix) * p.cin + c0 + a_ck[j] : zsrc;
+                glds16(src, as + j * 8 * BK);
             }
         } else {
             const bool first = k0 < p.c1;
-            const u16* src = first ? p.a : p.a2;
+            const u16* base = first ? p.a : p.a2;
             const int64_t ld = first ? p.lda : p.lda2;
-            const int kk = (first ? k0 : k0 - p.c1) + cc * 8;
+            const int kk = first ? k0 : k0 - p.c1;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (a_b[i] >= 0) v = *(const u16x8*)(src + (int64_t)a_b[i] * ld + kk);
-                ra[i] = v;
+            for (int j = 0; j < AI; ++j) {
+                const u16* src = a_b[j] >= 0 ? base + (int64_t)a_b[j] * ld + kk + a_ck[j] : zsrc;
+                glds16(src, as + j * 8 * BK);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *(const u16x8*)(p.w + (int64_t)(n0 + rr + 32 * i) * p.K + k0 + cc * 8);
-    };
-    auto store_tile = [&](int buf) {
-        u16* as = As + buf * BM * LDSK;
-        u16* bs = Bs + buf * BN * LDSK;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) *(u16x8*)(as + (rr + 32 * i) * LDSK + cc * 8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i) *(u16x8*)(bs + (rr + 32 * i) * LDSK + cc * 8) = rb[i];
+        for (int j = 0; j < BI; ++j) glds16(b_src[j] + k0, bs + j * 8 * BK);
     };
 
     f32x16 acc[FN][FM];
@@ -140,29 +162,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = p.K / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int frow = lane & 31, fsw = (lane >> 1) & 7, fhalf = lane >> 5;  // (row>>1)&7 == (lane>>1)&7: tile rows are 32-aligned
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nkt) issue_tile(s, s);
+    int cur = 0, nxt = D % STAGES;  // stage of tile kt / of tile kt+D
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const u16* as = As + cur * BM * LDSK + (wm * WM + frow) * LDSK + fk;
-        const u16* bs = Bs + cur * BN * LDSK + (wn * WN + frow) * LDSK + fk;
+        // tile kt must have landed; up to D-1 younger tiles stay in flight across the barrier
+        const int pending = (nkt - 1 - kt) < (D - 1) ? (nkt - 1 - kt) : (D - 1);
+        if (D >= 3 && pending == 2) wait_vm_then_barrier<2 * (AI + BI)>();
+        else if (D >= 2 && pending == 1) wait_vm_then_barrier<AI + BI>();
+        else wait_vm_then_barrier<0>();
+        // every wave is past its reads of the stage tile kt+D goes to (it held tile kt-1)
+        if (kt + D < nkt && !(p.debug & 1)) issue_tile(kt + D, nxt);
+        const u16* as = As + cur * BM * BK + (wm * WM + frow) * BK;
+        const u16* bs = Bs + cur * BN * BK + (wn * WN + frow) * BK;
+        if (!(p.debug & 2))
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            const int co = ((ks * 2 + fhalf) ^ fsw) * 8;
             u16x8 xf[FM], wf[FN];
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[j] = *(const u16x8*)(as + j * 32 * LDSK + ks * 16);
+            for (int j = 0; j < FM; ++j) xf[j] = *(const u16x8*)(as + j * 32 * BK + co);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[i] = *(const u16x8*)(bs + i * 32 * LDSK + ks * 16);
+            for (int i = 0; i < FN; ++i) wf[i] = *(const u16x8*)(bs + i * 32 * BK + co);
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int j = 0; j < FM; ++j) acc[i][j] = mfma_32x32x16(wf[i], xf[j], acc[i][j]);
         }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
-        __syncthreads();
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
 
     // ---- epilogue: lane holds, per (fn, fm, quad), channels n..n+3 of row m
@@ -241,20 +271,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * LDSK * (int)sizeof(u16);
+    constexpr int smem = STAGES * (BM + BN) * BK * (int)sizeof(u16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     GemmArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = a.Npad / BN;
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), smem, st, g);
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV>), dim3(g.tiles_m * g.tiles_n),
+                dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
     return 0;
+}
+
+// Tile configurations (id: BM x BN, waves, LDS stages -> LDS bytes, resident blocks per CU).
+// Which one wins depends on M, N, K and on how many workgroups the problem yields (measured: tools/bench_ops.py);
+// pcdms_amd.ops autotunes per problem shape at warm-up, id 0 = the static heuristic below.
+template <bool CONV>
+int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
+    switch (tile) {
+        case 1: return launch_gemm<256, 128, 4, 2, 3, CONV>(a, st);   // 8 waves, 144 KiB, 1 block / CU
+        case 2: return launch_gemm<64, 64, 2, 2, 2, CONV>(a, st);     // 4 waves,  32 KiB, 4+ blocks / CU
+        case 3: return launch_gemm<256, 64, 4, 2, 2, CONV>(a, st);    // 8 waves,  80 KiB, 2 blocks / CU
+        case 4: return launch_gemm<128, 128, 2, 2, 2, CONV>(a, st);   // 4 waves,  64 KiB, 2 blocks / CU
+        case 5: return launch_gemm<128, 64, 2, 2, 2, CONV>(a, st);    // 4 waves,  48 KiB, 3 blocks / CU
+        case 6: return launch_gemm<256, 64, 4, 2, 3, CONV>(a, st);    // 8 waves, 120 KiB, 1 block / CU
+        case 7: return launch_gemm<128, 128, 2, 2, 3, CONV>(a, st);   // 4 waves,  96 KiB, 1 block / CU
+        case 8: return launch_gemm<64, 64, 2, 2, 4, CONV>(a, st);     // 4 waves,  64 KiB, 2 blocks / CU
+        case 9: return launch_gemm<256, 128, 4, 2, 2, CONV>(a, st);   // 8 waves,  96 KiB, 1 block / CU
+        case 10: return launch_gemm<128, 64, 2, 2, 3, CONV>(a, st);   // 4 waves,  72 KiB, 2 blocks / CU
+        default: return -1;
+    }
 }
 }  // namespace
 
@@ -286,6 +338,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.out2 = (u16*)p->out2;
     a.ldo2 = p->ldo2;
     a.tiles_m = a.tiles_n = 0;
+    a.debug = p->tile >> 8;
     if (p->conv) {
         if (p->cin % BK || p->K != 9 * p->cin || (p->stride != 1 && p->stride != 2) || p->a2) return -1;
         if (p->upsample && p->stride != 1) return -1;
@@ -296,21 +349,19 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (p->epilogue == PCDM_EPI_GEGLU && (!p->bias || p->Npad % 128 || p->N * 2 > p->Npad)) return -1;
     if (p->epilogue == PCDM_EPI_SPLIT_VT && (!p->out2 || p->vt_col0 % 4)) return -1;
     hipStream_t st = (hipStream_t)s;
-    int tile = p->tile;
-    if (p->epilogue == PCDM_EPI_GEGLU) tile = 1;
+    int tile = p->tile & 0xff;
+    const bool n128 = p->Npad % 128 == 0;
+    const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9;
+    if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128) return -1;  // GEGLU pairs need a 64-wide wave tile
     if (tile == 0) {
-        // 128-row tiles unless the problem is too small to fill 256 CUs with them
-        const bool n128 = p->Npad % 128 == 0;
-        const int64_t big = (int64_t)((p->M + 127) / 128) * (p->Npad / (n128 ? 128 : 64));
-        tile = big >= 192 ? (n128 ? 1 : 3) : 2;
+        const int64_t t256 = (int64_t)((p->M + 255) / 256) * (p->Npad / 128);
+        const int64_t t128 = (int64_t)((p->M + 127) / 128) * (p->Npad / 128);
+        if (n128 && t256 >= 200) tile = 1;
+        else if (n128 && (t128 >= 160 || p->epilogue == PCDM_EPI_GEGLU)) tile = 4;
+        else if (!n128 && (int64_t)((p->M + 127) / 128) * (p->Npad / 64) >= 256) tile = 5;
+        else tile = 2;
+    } else if (needs128 && !n128) {
+        return -1;
     }
-    if (tile == 1 && p->Npad % 128) return -1;
-    if (p->conv) {
-        if (tile == 1) return launch_gemm<128, 128, true>(a, st);
-        if (tile == 3) return launch_gemm<128, 64, true>(a, st);
-        return launch_gemm<64, 64, true>(a, st);
-    }
-    if (tile == 1) return launch_gemm<128, 128, false>(a, st);
-    if (tile == 3) return launch_gemm<128, 64, false>(a, st);
-    return launch_gemm<64, 64, false>(a, st);
+    return p->conv ? dispatch_tile<true>(tile, a, st) : dispatch_tile<false>(tile, a, st);
 }

@@ -41,9 +41,29 @@ __device__ __forceinline__ u16 f2bf(float f) {
 #else
 #define PCDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define PCDM_KERNEL_NAME(...) __VA_ARGS__
+// hipGetLastError() first: drop any stale error left by an unrelated runtime call on this thread, so the
+// PCDM_CHECK_LAUNCH() after the launch reports this launch only
 #define PCDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    kernel<<<(grid), (block), (smem), (stream)>>>(__VA_ARGS__)
+    ((void)hipGetLastError(), kernel<<<(grid), (block), (smem), (stream)>>>(__VA_ARGS__))
 #endif
+
+// ---- async global -> LDS copy (LDS-DMA, global_load_lds_dwordx4) -----------------------------
+// Each lane supplies its own 16-byte GLOBAL source; the destination is wave-uniform:
+// lane i lands at lds_wave_base + 16*i.  Completion is tracked by vmcnt: call glds_wait() before the
+// barrier that publishes the tile.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef PCDM_EMU
+    memcpy((char*)lds_wave_base + 16 * emu::lane_id(), gsrc, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void glds_wait() {
+#ifndef PCDM_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 
 // ---- math ----------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_exp2(float x) {

@@ -19,6 +19,7 @@ from ._lib import GemmParams
 EPI_STORE, EPI_GEGLU, EPI_SPLIT_VT, EPI_NCHW_F32 = 0, 1, 2, 3
 BF16 = torch.bfloat16
 LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
+AUTOTUNE = True                    # pick the GEMM tile configuration per problem shape at first use (GPU only)
 
 
 def _stream(t: torch.Tensor) -> Optional[int]:
@@ -179,16 +180,50 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     if out2 is not None:
         p.out2 = _ptr(out2)
         p.ldo2 = out2.shape[-1]
+    stream = _stream(a)
+    if tile == 0 and AUTOTUNE and a.is_cuda:
+        key = (M, pw.Npad, pw.K, p.conv, p.stride, p.upsample, epilogue, a2 is not None, residual is not None)
+        tile = _TUNED.get(key, 0)
+        if tile == 0 and not torch.cuda.is_current_stream_capturing():
+            tile = _TUNED[key] = _autotune(p, stream, pw, epilogue)
     p.tile = tile
     if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _chk(_lib.lib().pcdm_gemm(C.byref(p), _stream(a)), "pcdm_gemm")
+        _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
         e1.record()
-        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv))))
+        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile)))
         return out
-    _chk(_lib.lib().pcdm_gemm(C.byref(p), _stream(a)), "pcdm_gemm")
+    _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
     return out
+
+
+N_TILE_CONFIGS = 10
+_TUNED: dict = {}
+
+
+def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int) -> int:
+    """Time every valid tile configuration of gemm.hip on this exact problem (HIP events on the launch
+    stream, 1 warm + 3 timed launches each) and return the fastest.  Runs once per problem shape, outside
+    graph capture; the launches are idempotent (same inputs, same output buffer)."""
+    fn = _lib.lib().pcdm_gemm
+    best, best_t = 0, float("inf")
+    for tile in range(1, N_TILE_CONFIGS + 1):
+        p.tile = tile
+        if fn(C.byref(p), stream) != 0:   # configuration not valid for this N / epilogue
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn(C.byref(p), stream)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = tile, t
+    if best == 0:
+        raise RuntimeError("no valid GEMM tile configuration")
+    return best
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,

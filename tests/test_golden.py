@@ -1,0 +1,99 @@
+"""Golden fixtures produced by the REFERENCE's own forward / __call__ (tests/golden/README in
+make_reference_wiring_fixtures.py).  CPU: the oracle reproduces them.  GPU: the HIP path reproduces them.
+
+Tolerances: the UNet fixture used fp32 inputs -> oracle must agree to fp32 round-off (1e-5).  The pipeline
+fixtures include the reference's hard-coded ``.half()`` casts of every UNet input (Appendix C-3), so the
+fp32 oracle agrees to 1e-2 rel-L2 over 4 steps; the bf16 HIP path to 5e-2.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.pipeline import stage2_sample
+from oracle.schedulers import DDIMOracle, UniPCOracle
+from oracle.unet import UNetConfig, synth_state_dict, unet_forward
+
+G = Path(__file__).resolve().parent / "golden"
+
+
+def _load(name):
+    z = np.load(G / name)
+    cfg = UNetConfig(block_out_channels=tuple(int(v) for v in z["block_out_channels"]),
+                     attention_head_dim=tuple(int(v) for v in z["attention_head_dim"]),
+                     cross_attention_dim=int(z["cross_attention_dim"]),
+                     projection_class_embeddings_input_dim=int(z["projection_class_embeddings_input_dim"]),
+                     sample_size=int(z["sample_size"]))
+    sd = synth_state_dict(cfg, seed=int(z["seed"]), random_affine=True)
+    from tests.golden.make_reference_wiring_fixtures import weights_checksum
+    if abs(weights_checksum(sd) - float(z["weights_checksum"])) > 1e-6 * float(z["weights_checksum"]):
+        pytest.skip(f"seeded weight generation differs from the fixture's (torch {z['torch_version']} vs {torch.__version__})")
+    return z, cfg, sd
+
+
+def _t(z, k):
+    return torch.from_numpy(np.asarray(z[k]))
+
+
+def _rel(a, b):
+    return ((a.float().cpu() - b).norm() / b.norm()).item()
+
+
+def test_oracle_reproduces_reference_forward():
+    z, cfg, sd = _load("ref_wiring_unet.npz")
+    eps = unet_forward(sd, cfg, _t(z, "sample"), torch.tensor(int(z["timestep"])), _t(z, "ehs"), _t(z, "class_labels"),
+                       _t(z, "pose"))
+    assert torch.allclose(eps, _t(z, "eps"), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["ddim", "unipc"])
+def test_oracle_reproduces_reference_pipeline(kind):
+    z, cfg, sd = _load(f"ref_wiring_pipeline_{kind}.npz")
+    sch = DDIMOracle() if kind == "ddim" else UniPCOracle()
+    trace = []
+    out = stage2_sample(sd, cfg, sch, masked_latents=_t(z, "masked_latents"), s_img_proj_f=_t(z, "s_img_proj_f"),
+                        st_pose_f=_t(z, "st_pose_f"), pred_t_img_embed=_t(z, "pred_t_img_embed"),
+                        latents=_t(z, "latents"), num_images_per_prompt=int(z["N"]), guidance_scale=2.0,
+                        num_inference_steps=int(z["steps"]))
+    assert _rel(out, _t(z, "final_latents")) < 1e-2, _rel(out, _t(z, "final_latents"))
+
+
+def _product_unet(cfg, sd, dev):
+    from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
+    from tests.test_unet import _kwargs
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    return m.to(dev)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_forward(gpu_backend):
+    z, cfg, sd = _load("ref_wiring_unet.npz")
+    dev = gpu_backend.device
+    m = _product_unet(cfg, sd, dev)
+    eps = m(_t(z, "sample").to(dev), torch.tensor(int(z["timestep"]), device=dev), _t(z, "ehs").to(dev),
+            class_labels=_t(z, "class_labels").to(dev), my_pose_cond=_t(z, "pose").to(dev)).sample
+    assert _rel(eps, _t(z, "eps")) < 2.5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ddim", "unipc"])
+def test_hip_reproduces_reference_pipeline(gpu_backend, kind):
+    from pcdms_amd.pipeline import Stage2_InpaintDiffusionPipeline
+    from pcdms_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
+    from tests.test_schedulers import SD21
+    z, cfg, sd = _load(f"ref_wiring_pipeline_{kind}.npz")
+    dev = gpu_backend.device
+    m = _product_unet(cfg, sd, dev)
+    sch = (DDIMScheduler if kind == "ddim" else UniPCMultistepScheduler).from_config(SD21)
+    pipe = Stage2_InpaintDiffusionPipeline(m, sch)
+    h, w = z["latents"].shape[-2:]
+    out = pipe(height=h * 8, width=w * 8, masked_latents=_t(z, "masked_latents").to(dev),
+               s_img_proj_f=_t(z, "s_img_proj_f").to(dev), st_pose_f=_t(z, "st_pose_f").to(dev),
+               pred_t_img_embed=_t(z, "pred_t_img_embed").to(dev), latents=_t(z, "latents").to(dev),
+               num_images_per_prompt=int(z["N"]), guidance_scale=2.0, num_inference_steps=int(z["steps"]),
+               output_type="latent").latents
+    assert _rel(out, _t(z, "final_latents")) < 5e-2, _rel(out, _t(z, "final_latents"))

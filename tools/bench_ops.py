@@ -56,8 +56,8 @@ def main():
         pw = ops.pack_conv3x3(torch.randn(Co, Ci, 3, 3) / math.sqrt(9 * Ci), torch.randn(Co), dev)
         out = torch.empty(B * H * W, Co, dtype=BF16, device=dev)
         cv = dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W)
-        for tile in ((0,) if args.quick else (1, 2, 3)):
-            if tile == 1 and pw.Npad % 128:
+        for tile in ((0,) if args.quick else (1, 2, 3, 4)):
+            if tile in (1, 4) and pw.Npad % 128:
                 continue
             t = timeit(lambda: ops.gemm(x, pw, out, conv=cv, tile=tile))
             rec(f"conv3x3 {Ci}->{Co} @{H}x{W} tile{tile}", t, flops=2.0 * B * H * W * Co * 9 * Ci)
@@ -69,8 +69,8 @@ def main():
         a = torch.randn(M, K, device=dev).to(BF16)
         pw = ops.pack_linear(torch.randn(N, K) / math.sqrt(K), torch.randn(N), dev)
         out = torch.empty(M, N, dtype=BF16, device=dev)
-        for tile in ((0,) if args.quick else (1, 2, 3)):
-            if tile == 1 and pw.Npad % 128:
+        for tile in ((0,) if args.quick else (1, 2, 3, 4)):
+            if tile in (1, 4) and pw.Npad % 128:
                 continue
             t = timeit(lambda: ops.gemm(a, pw, out, tile=tile))
             rec(f"linear M{M} K{K} N{N} tile{tile}", t, flops=2.0 * M * K * N)
