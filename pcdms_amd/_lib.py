@@ -10,6 +10,11 @@ import ctypes as C
 from pathlib import Path
 from typing import Optional
 
+# torch FIRST: libpcdm.so needs libamdhip64.so.7; PyTorch-ROCm bundles its own copy, and the process must end up
+# with ONE HIP runtime (torch's), i.e. torch's must already be loaded when libpcdm.so is dlopen'ed.  Loading
+# libpcdm.so first pulls /opt/rocm's runtime in beside torch's and every launch then fails with hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libpcdm.so"
 
