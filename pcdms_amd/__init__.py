@@ -1,0 +1,12 @@
+"""pcdms_amd -- the PCDMs stage-2 pose-conditioned inpainting denoise loop, MI355X (gfx950) native.
+
+Drop-in objects for the reference's ``pipe.unet`` / ``pipe.scheduler``
+(/root/reference/stage2_batchtest_inpaint_model.py:125-132) backed by hand-written HIP kernels in
+``pcdms_amd/lib/libpcdm.so`` (C-ABI: include/pcdm.h).  See DESIGN.md / INTEGRATION.md.
+"""
+from .parallel import run_sharded, split_list_into_chunks  # noqa: F401
+from .pipeline import Stage2_InpaintDiffusionPipeline, Stage2_InpaintDiffusionPipelineOutput  # noqa: F401
+from .schedulers import DDIMScheduler, DDPMScheduler, UniPCMultistepScheduler  # noqa: F401
+from .unet import Stage2_InapintUNet2DConditionModel, Stage2InpaintUNet, UNet2DConditionOutput  # noqa: F401
+
+__version__ = "0.1.0"

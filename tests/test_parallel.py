@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: world_size-2 gloo processes, pairs sharded like the reference, one all-gather."""
+from __future__ import annotations
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pcdms_amd.parallel import chunk_index_ranges, run_sharded, split_list_into_chunks
+
+
+def test_split_matches_reference_semantics():
+    # remainder folded into the last chunk (ref stage2_batchtest_inpaint_model.py:25-31)
+    assert split_list_into_chunks(list(range(10)), 3) == [[0, 1, 2], [3, 4, 5], [6, 7, 8, 9]]
+    assert split_list_into_chunks(list(range(8)), 8) == [[i] for i in range(8)]
+    assert split_list_into_chunks(list(range(9)), 2) == [[0, 1, 2, 3], [4, 5, 6, 7, 8]]
+    assert split_list_into_chunks([1, 2], 4) == [[1], [2], [], []]   # the reference raises here; we stay total
+    assert [list(r) for r in chunk_index_ranges(5, 2)] == [[0, 1], [2, 3, 4]]
+    with pytest.raises(ValueError):
+        split_list_into_chunks([1], 0)
+
+
+def _sample(pair):
+    g = torch.Generator().manual_seed(int(pair))
+    return torch.randn(2, 4, 3, 5, generator=g) + pair
+
+
+_sample.example_output = torch.zeros(2, 4, 3, 5)
+
+
+def _worker(rank, world, port, npairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"n": 0}
+    orig = dist.all_gather
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    dist.all_gather = counting
+    try:
+        res = run_sharded(list(range(npairs)), _sample)
+    finally:
+        dist.all_gather = orig
+    ok = len(res) == npairs and all(torch.equal(r, _sample(i)) for i, r in enumerate(res)) and calls["n"] == (1 if npairs else 0)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("npairs", [5, 1])
+def test_run_sharded_gloo_world2(npairs):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, npairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_run_sharded_single_process():
+    res = run_sharded([3, 4], _sample)
+    assert torch.equal(res[1], _sample(4))
