@@ -74,6 +74,9 @@ typedef struct pcdm_gemm_params {
     int64_t ldo;
     void* out2;
     int64_t ldo2;
+    int32_t split_k;   /* > 1: split K over split_k workgroups per tile (PCDM_EPI_STORE only); partial sums in ws */
+    float* ws;         /* fp32 workspace, >= split_k * M * Npad floats */
+    int64_t ws_floats;
     int32_t tile;      /* 0 = heuristic; 1..10 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
 } pcdm_gemm_params;
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);

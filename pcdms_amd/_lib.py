@@ -36,6 +36,7 @@ class GemmParams(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("res_mod", C.c_int32),
         ("epilogue", C.c_int32), ("vt_col0", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out2", C.c_void_p), ("ldo2", C.c_int64),
+        ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("tile", C.c_int32),
     ]
 

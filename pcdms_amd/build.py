@@ -43,7 +43,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
         s = CSRC / src
         o = LIBDIR / (src + ".o")
         if force or _stale(o, [s, *headers]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
                    "-Wno-unused-result", "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -49,6 +49,8 @@ struct GemmArgs {
     u16* out2;
     int64_t ldo2;
     int tiles_m, tiles_n;
+    int split_k;   // > 1: K range split over split_k workgroups per tile, fp32 partials to ws, reduced by splitk_reduce_kernel
+    float* ws;
     int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs
 };
 
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ksplit = wg / ntiles, tile_id = wg - ksplit * ntiles;  // neighbours = same K slice, adjacent N tiles
+    const int tile_m = tile_id / p.tiles_n, tile_n = tile_id - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- LDS-DMA staging coordinates.  Wave-instruction j of wave w fills tile rows (w*AI+j)*8 .. +7:
@@ -122,8 +126,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     const int Hv = p.Hi << p.upsample, Wv = p.Wi << p.upsample;
     const u16* zsrc = (const u16*)g_zero16;
 
+    int kt0 = 0;  // first K-tile of this workgroup's K slice (set below)
     auto issue_tile = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+        const int k0 = (kt0 + kt) * BK;
         u16* as = As + buf * BM * BK + (wave * AI) * 8 * BK;
         u16* bs = Bs + buf * BN * BK + (wave * BI) * 8 * BK;
         if (CONV) {
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = p.K / BK;
+    const int nkt_all = p.K / BK;
+    kt0 = (int)((int64_t)ksplit * nkt_all / p.split_k);
+    const int nkt = (int)((int64_t)(ksplit + 1) * nkt_all / p.split_k) - kt0;  // this workgroup's K-tiles
     const int frow = lane & 31, fsw = (lane >> 1) & 7, fhalf = lane >> 5;  // (row>>1)&7 == (lane>>1)&7: tile rows are 32-aligned
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -197,6 +204,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 
     // ---- epilogue: lane holds, per (fn, fm, quad), channels n..n+3 of row m
     const int half = lane >> 5;
+    if (p.split_k > 1) {  // raw fp32 partial sums; bias / temb / residual are applied by the reduce kernel
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + wm * WM + j * 32 + (lane & 31);
+            if (m >= p.M) continue;
+            float* wr = p.ws + ((int64_t)ksplit * p.M + m) * p.Npad + n0 + wn * WN + 4 * half;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 v = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+                    *(f32x4*)(wr + i * 32 + 8 * rg) = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = m0 + wm * WM + j * 32 + (lane & 31);
@@ -271,6 +294,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+// out[m, n..n+3] = epilogue( sum_s ws[s][m][n..n+3] ); one thread per (row, channel quad); PCDM_EPI_STORE only
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const int nq = p.N / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.M * nq) return;
+    const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.split_k; ++s) v += *(const f32x4*)(p.ws + ((int64_t)s * p.M + m) * p.Npad + n);
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n);
+    if (p.residual) {
+        const u16x4 rv = *(const u16x4*)(p.residual + (int64_t)(m % p.res_mod) * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+    }
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+    *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
+}
+
 template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = STAGES * (BM + BN) * BK * (int)sizeof(u16);
@@ -283,9 +327,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     GemmArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = a.Npad / BN;
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV>), dim3(g.tiles_m * g.tiles_n),
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV>), dim3(g.tiles_m * g.tiles_n * g.split_k),
                 dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
+    if (g.split_k > 1) {
+        const int64_t n = (int64_t)g.M * (g.N / 4);
+        PCDM_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+        PCDM_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -339,6 +388,12 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.ldo2 = p->ldo2;
     a.tiles_m = a.tiles_n = 0;
     a.debug = p->tile >> 8;
+    a.split_k = p->split_k > 1 ? p->split_k : 1;
+    a.ws = p->ws;
+    if (a.split_k > 1) {
+        if (p->epilogue != PCDM_EPI_STORE || !p->ws || a.split_k > p->K / BK || a.split_k > 64) return -1;
+        if (p->ws_floats < (int64_t)a.split_k * p->M * p->Npad) return -1;
+    }
     if (p->conv) {
         if (p->cin % BK || p->K != 9 * p->cin || (p->stride != 1 && p->stride != 2) || p->a2) return -1;
         if (p->upsample && p->stride != 1) return -1;

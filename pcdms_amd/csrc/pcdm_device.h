@@ -26,6 +26,10 @@ __device__ __forceinline__ float bf2f(u16 v) {
     return __builtin_bit_cast(float, u);
 }
 __device__ __forceinline__ u16 f2bf(float f) {
+#ifndef PCDM_EMU
+    // gfx950 has a hardware RNE convert (v_cvt_pk_bf16_f32); hipcc emits it for the native __bf16 cast
+    return __builtin_bit_cast(u16, (__bf16)f);
+#endif
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);

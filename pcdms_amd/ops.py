@@ -137,7 +137,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
-         use_bias: bool = True) -> torch.Tensor:
+         use_bias: bool = True, split_k: int = 1) -> torch.Tensor:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``."""
     p = GemmParams()
@@ -181,47 +181,80 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.out2 = _ptr(out2)
         p.ldo2 = out2.shape[-1]
     stream = _stream(a)
+    split = 1
     if tile == 0 and AUTOTUNE and a.is_cuda:
         key = (M, pw.Npad, pw.K, p.conv, p.stride, p.upsample, epilogue, a2 is not None, residual is not None)
-        tile = _TUNED.get(key, 0)
+        tile, split = _TUNED.get(key, (0, 1))
         if tile == 0 and not torch.cuda.is_current_stream_capturing():
-            tile = _TUNED[key] = _autotune(p, stream, pw, epilogue)
+            tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device)
+    elif split_k > 1:
+        split = split_k
     p.tile = tile
+    if split > 1:
+        ws = _splitk_ws(a.device, split * M * pw.Npad)
+        p.split_k, p.ws, p.ws_floats = split, ws.data_ptr(), ws.numel()
     if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
         e1.record()
-        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile)))
+        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split)))
         return out
     _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
     return out
 
 
-N_TILE_CONFIGS = 10
+# gemm.hip dispatch_tile(): id -> (BM, BN)
+TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
+               8: (64, 64), 9: (256, 128), 10: (128, 64)}
 _TUNED: dict = {}
+_WS: dict = {}
 
 
-def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int) -> int:
-    """Time every valid tile configuration of gemm.hip on this exact problem (HIP events on the launch
-    stream, 1 warm + 3 timed launches each) and return the fastest.  Runs once per problem shape, outside
-    graph capture; the launches are idempotent (same inputs, same output buffer)."""
+def _splitk_ws(device, floats: int) -> torch.Tensor:
+    """fp32 split-K workspace (one per device; only grows outside graph capture)."""
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < floats:
+        if ws is not None and device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("split-K workspace would grow during graph capture")
+        ws = _WS[device] = torch.empty(max(floats, 1 << 24), dtype=torch.float32, device=device)
+    return ws
+
+
+def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int, device):
+    """Time every valid (tile configuration, split-K factor) of gemm.hip on this exact problem (HIP events on
+    the launch stream, 1 warm + 3 timed launches each) and return the fastest.  Runs once per problem shape,
+    outside graph capture; the launches are idempotent (same inputs, same output buffer)."""
     fn = _lib.lib().pcdm_gemm
-    best, best_t = 0, float("inf")
-    for tile in range(1, N_TILE_CONFIGS + 1):
-        p.tile = tile
-        if fn(C.byref(p), stream) != 0:   # configuration not valid for this N / epilogue
+    nkt = pw.K // 64
+    best, best_t = (0, 1), float("inf")
+    for tile, (bm, bn) in TILE_SHAPES.items():
+        ntiles = -(-p.M // bm) * (pw.Npad // bn if pw.Npad % bn == 0 else 0)
+        if ntiles == 0:
             continue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            fn(C.byref(p), stream)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1)
-        if t < best_t:
-            best, best_t = tile, t
-    if best == 0:
+        splits = [1]
+        if epilogue == EPI_STORE:   # split K only when the tile grid alone cannot fill the 256 CUs
+            splits += [s for s in (2, 3, 4, 6, 8, 12, 16) if ntiles * s <= 1024 and nkt // s >= 4 and ntiles < 512]
+        for sk in splits:
+            p.tile = tile
+            if sk > 1:
+                ws = _splitk_ws(device, sk * p.M * pw.Npad)
+                p.split_k, p.ws, p.ws_floats = sk, ws.data_ptr(), ws.numel()
+            else:
+                p.split_k, p.ws, p.ws_floats = 0, None, 0
+            if fn(C.byref(p), stream) != 0:   # configuration not valid for this N / epilogue
+                break
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn(C.byref(p), stream)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = (tile, sk), t
+    p.split_k, p.ws, p.ws_floats = 0, None, 0
+    if best[0] == 0:
         raise RuntimeError("no valid GEMM tile configuration")
     return best
 

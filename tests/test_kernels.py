@@ -103,6 +103,25 @@ def test_gemm_linear_bias_residual_rowvec(backend):
         close(out, ref)
 
 
+def test_gemm_split_k(backend):
+    """K split over several workgroups per tile + fp32 reduce kernel (small-M / huge-K level-3 convs)."""
+    dev = backend.device
+    cases = [(70, 256, 64, 2, 2), (130, 512, 128, 4, 3)] if backend.is_emu else \
+        [(704, 11520, 1280, 2, 8), (704, 23040, 1280, 4, 6), (2816, 11520, 1280, 1, 2), (999, 1280, 320, 5, 3)]
+    for (M, K, N, tile, sk) in cases:
+        a = rnd(M, K, seed=15)
+        w = rnd(N, K, seed=16, scale=1 / math.sqrt(K))
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(17))
+        res = rnd(M, N, seed=18)
+        rowvec = torch.randn(1, N, generator=torch.Generator().manual_seed(19))
+        pw = ops.pack_linear(w.float(), bias, dev)
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.gemm(a.to(dev), pw, out, rowvec=rowvec.to(dev), rows_per_batch=M, residual=res.to(dev), res_mod=M,
+                 tile=tile, split_k=sk)
+        backend.sync()
+        close(out, a.float() @ w.float().t() + bias + res.float() + rowvec)
+
+
 def test_gemm_two_source_and_broadcast_residual(backend):
     dev = backend.device
     M, K1, K2, N = (96, 64, 128, 64) if backend.is_emu else (11264, 1280, 640, 640)
