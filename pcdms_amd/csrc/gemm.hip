@@ -68,7 +68,26 @@ __device__ __forceinline__ void wait_vm_then_barrier() {
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+#ifndef PCDM_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void wait_lds_then_barrier() {  // this wave's ds_reads are complete, then raw s_barrier
+#ifdef PCDM_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// STAG (8-wave tiles only): the two waves that share a SIMD (w and w+4) run half a K-tile out of phase --
+// while one is in its MFMA segment (16 back-to-back MFMAs on fragments held in registers) the other is in its
+// memory segment (LDS-DMA issue for tile t+D, 16 ds_read_b128 of tile t), two raw barriers per K-tile
+// (MI355X_MICROARCH.md "Two waves per SIMD").  Without it every wave alternates memory and matrix phases in
+// lockstep and the two pipes are used one after the other (profiles/r1_gemm_ablation.txt: full ~ noload + nomfma).
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
@@ -79,7 +98,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     u16* As = (u16*)smem;                    // [STAGES][BM][64]   (unpadded, XOR-swizzled 16-byte chunks)
     u16* Bs = As + STAGES * BM * BK;         // [STAGES][BN][64]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform -> LDS bases / branches in SGPRs
     const int wm = wave / WGN, wn = wave - wm * WGN;
 
     // XCD-aware bijective remap of the linear workgroup id
@@ -91,40 +111,55 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     const int tile_m = tile_id / p.tiles_n, tile_n = tile_id - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- LDS-DMA staging coordinates.  Wave-instruction j of wave w fills tile rows (w*AI+j)*8 .. +7:
-    // lane i -> LDS slot i = (row i>>3, position i&7); position q of row r holds global chunk q ^ ((r>>1)&7)
-    // (swizzle on the SOURCE address, linear destination; the same XOR is applied on the fragment reads).
+    // ---- LDS-DMA staging (buffer_load_dwordx4 ... lds).  Wave-instruction j of wave w fills tile rows
+    // (w*AI+j)*8 .. +7: lane i -> LDS slot i = (row i>>3, position i&7); position q of row r holds global chunk
+    // q ^ ((r>>1)&7) (swizzle on the SOURCE offset, linear destination; the same XOR is applied on the fragment
+    // reads).  Addressing = one buffer descriptor per operand (SGPRs) + a per-lane 32-bit byte offset that is
+    // CONSTANT over the K loop + a wave-uniform SGPR offset that advances with the K-tile: no per-lane address
+    // arithmetic in the steady state.  Out-of-range offsets return zeros (hardware bounds check), which is how
+    // the implicit-GEMM zero padding (3x3 halo) is produced.
     const int srow = lane >> 3, spos = lane & 7;
-    int a_b[AI], a_y[AI], a_x[AI], a_ck[AI];  // conv: batch / out y / out x ; linear: a_b = row or -1
+    constexpr uint32_t kOOB = 0x80000000u;
+    uint32_t a_off[AI], a_off2[AI];   // byte offsets: linear: row*lda (+chunk) in a / a2; conv: centre tap pixel
+    int a_mask[AI];                   // conv: bit t set <=> tap t (= ky*3+kx) of this row is inside the image
+    int a_b[AI], a_y[AI], a_x[AI];    // conv + upsample only: coordinates for the per-tile gather
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
         const int rl = (wave * AI + j) * 8 + srow;
-        const int m = m0 + rl;
-        a_ck[j] = (spos ^ ((rl >> 1) & 7)) * 8;
-        if (m < p.M) {
-            if (CONV) {
-                const int hw = p.Ho * p.Wo;
-                const int b = m / hw, rem = m - b * hw;
-                a_b[j] = b;
-                a_y[j] = rem / p.Wo;
-                a_x[j] = rem - a_y[j] * p.Wo;
-            } else {
-                a_b[j] = m;
-                a_y[j] = a_x[j] = 0;
+        int m = m0 + rl;
+        const uint32_t ck = (uint32_t)(spos ^ ((rl >> 1) & 7)) * 16u;   // bytes
+        const bool mvalid = m < p.M;
+        if (!mvalid) m = p.M - 1;    // rows >= M are never stored: any in-range data will do
+        a_off2[j] = 0; a_mask[j] = 0; a_b[j] = a_y[j] = a_x[j] = 0;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / p.Wo, x = rem - y * p.Wo;
+            a_b[j] = b; a_y[j] = y; a_x[j] = x;
+            // offset of tap (0,0) relative to a descriptor base shifted back by (Wi+1) pixels (see rs_a below)
+            a_off[j] = (uint32_t)((((int64_t)b * p.Hi + y * p.stride) * p.Wi + x * p.stride) * p.cin * 2) + ck;
+            const int Hv_ = p.Hi << p.upsample, Wv_ = p.Wi << p.upsample;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int iy = y * p.stride + tp / 3 - 1, ix = x * p.stride + tp % 3 - 1;
+                if (iy >= 0 && iy < Hv_ && ix >= 0 && ix < Wv_) a_mask[j] |= 1 << tp;
             }
         } else {
-            a_b[j] = -1;
-            a_y[j] = a_x[j] = 0;
+            a_off[j] = (uint32_t)((int64_t)m * p.lda * 2) + ck;
+            a_off2[j] = (uint32_t)((int64_t)m * p.lda2 * 2) + ck;
         }
     }
-    const u16* b_src[BI];
+    uint32_t b_off[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int rl = (wave * BI + j) * 8 + srow;
-        b_src[j] = p.w + (int64_t)(n0 + rl) * p.K + (spos ^ ((rl >> 1) & 7)) * 8;
+        b_off[j] = (uint32_t)((int64_t)(n0 + rl) * p.K * 2) + (uint32_t)(spos ^ ((rl >> 1) & 7)) * 16u;
     }
-    const int Hv = p.Hi << p.upsample, Wv = p.Wi << p.upsample;
-    const u16* zsrc = (const u16*)g_zero16;
+    // conv: descriptor base = a - (Wi+1) pixels, so that tap (ky,kx) is the NON-NEGATIVE uniform offset
+    // (ky*Wi + kx)*cin*2; the bytes in front of the tensor are never touched (those taps are masked)
+    const BufRsrc rs_a = make_buf_rsrc(CONV ? (const char*)p.a - (int64_t)(p.Wi + 1) * p.cin * 2 : (const char*)p.a);
+    const BufRsrc rs_a2 = make_buf_rsrc(p.a2 ? (const void*)p.a2 : (const void*)p.a);
+    const BufRsrc rs_w = make_buf_rsrc(p.w);
 
     int kt0 = 0;  // first K-tile of this workgroup's K slice (set below)
     auto issue_tile = [&](int kt, int buf) {
@@ -134,28 +169,33 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         if (CONV) {
             const int tap = k0 / p.cin, c0 = k0 - tap * p.cin;
             const int ky = tap / 3, kx = tap - ky * 3;
+            if (!p.upsample) {
+                const uint32_t soff = (uint32_t)(((ky * p.Wi + kx) * p.cin + c0) * 2);
 #pragma unroll
-            for (int j = 0; j < AI; ++j) {
-                int iy = a_y[j] * p.stride + ky - 1, ix = a_x[j] * p.stride + kx - 1;
-                const bool ok = a_b[j] >= 0 && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-                iy >>= p.upsample;
-                ix >>= p.upsample;
-                const u16* src = ok ? p.a + (((int64_t)a_b[j] * p.Hi + iy) * p.Wi + ix) * p.cin + c0 + a_ck[j] : zsrc;
-                glds16(src, as + j * 8 * BK);
+                for (int j = 0; j < AI; ++j)
+                    buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? a_off[j] : kOOB, soff, as + j * 8 * BK);
+            } else {   // nearest-x2 upsample folded in: source pixel (iy>>1, ix>>1), not affine in the tap
+#pragma unroll
+                for (int j = 0; j < AI; ++j) {
+                    const int iy = (a_y[j] + ky - 1) >> 1, ix = (a_x[j] + kx - 1) >> 1;
+                    const uint32_t ck = (uint32_t)(spos ^ ((((wave * AI + j) * 8 + srow) >> 1) & 7)) * 16u;
+                    const uint32_t off = (uint32_t)((((int64_t)a_b[j] * p.Hi + iy + 1) * p.Wi + ix + 1) * p.cin * 2) + ck;
+                    buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? off : kOOB, (uint32_t)(c0 * 2), as + j * 8 * BK);
+                }
             }
         } else {
             const bool first = k0 < p.c1;
-            const u16* base = first ? p.a : p.a2;
-            const int64_t ld = first ? p.lda : p.lda2;
-            const int kk = first ? k0 : k0 - p.c1;
+            const uint32_t soff = (uint32_t)((first ? k0 : k0 - p.c1) * 2);
+            if (first) {
 #pragma unroll
-            for (int j = 0; j < AI; ++j) {
-                const u16* src = a_b[j] >= 0 ? base + (int64_t)a_b[j] * ld + kk + a_ck[j] : zsrc;
-                glds16(src, as + j * 8 * BK);
+                for (int j = 0; j < AI; ++j) buf_glds16(rs_a, a_off[j], soff, as + j * 8 * BK);
+            } else {
+#pragma unroll
+                for (int j = 0; j < AI; ++j) buf_glds16(rs_a2, a_off2[j], soff, as + j * 8 * BK);
             }
         }
 #pragma unroll
-        for (int j = 0; j < BI; ++j) glds16(b_src[j] + k0, bs + j * 8 * BK);
+        for (int j = 0; j < BI; ++j) buf_glds16(rs_w, b_off[j], (uint32_t)(k0 * 2), bs + j * 8 * BK);
     };
 
     f32x16 acc[FN][FM];
@@ -170,36 +210,91 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     kt0 = (int)((int64_t)ksplit * nkt_all / p.split_k);
     const int nkt = (int)((int64_t)(ksplit + 1) * nkt_all / p.split_k) - kt0;  // this workgroup's K-tiles
     const int frow = lane & 31, fsw = (lane >> 1) & 7, fhalf = lane >> 5;  // (row>>1)&7 == (lane>>1)&7: tile rows are 32-aligned
+    if constexpr (STAG) {
+        static_assert(NW == 8 && D == 2, "staggered schedule: 8 waves, 3 stages");
+        constexpr int PW = AI + BI;  // LDS-DMA instructions per wave per K-tile
+        const bool grpB = wave >= NW / 2;
 #pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nkt) issue_tile(s, s);
-    int cur = 0, nxt = D % STAGES;  // stage of tile kt / of tile kt+D
-    for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt must have landed; up to D-1 younger tiles stay in flight across the barrier
-        const int pending = (nkt - 1 - kt) < (D - 1) ? (nkt - 1 - kt) : (D - 1);
-        if (D >= 3 && pending == 2) wait_vm_then_barrier<2 * (AI + BI)>();
-        else if (D >= 2 && pending == 1) wait_vm_then_barrier<AI + BI>();
-        else wait_vm_then_barrier<0>();
-        // every wave is past its reads of the stage tile kt+D goes to (it held tile kt-1)
-        if (kt + D < nkt && !(p.debug & 1)) issue_tile(kt + D, nxt);
-        const u16* as = As + cur * BM * BK + (wm * WM + frow) * BK;
-        const u16* bs = Bs + cur * BN * BK + (wn * WN + frow) * BK;
-        if (!(p.debug & 2))
+        for (int s = 0; s < D; ++s)
+            if (s < nkt) issue_tile(s, s);
+        if (nkt > 1) wait_vm_then_barrier<PW>(); else wait_vm_then_barrier<0>();   // tile 0 landed for everyone
+        if (grpB) wait_vm_then_barrier<PW>();   // group B lags one phase (vmcnt value irrelevant: already satisfied)
+        int cur = 0, nxt = D % STAGES;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // ---- memory segment: DMA for tile kt+D, all fragments of tile kt -> registers
+            if (kt + D < nkt) issue_tile(kt + D, nxt);
+            const u16* as = As + cur * BM * BK + (wm * WM + frow) * BK;
+            const u16* bs = Bs + cur * BN * BK + (wn * WN + frow) * BK;
+            u16x8 xf[BK / 16][FM], wf[BK / 16][FN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int co = ((ks * 2 + fhalf) ^ fsw) * 8;
-            u16x8 xf[FM], wf[FN];
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int co = ((ks * 2 + fhalf) ^ fsw) * 8;
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[j] = *(const u16x8*)(as + j * 32 * BK + co);
+                for (int j = 0; j < FM; ++j) xf[ks][j] = *(const u16x8*)(as + j * 32 * BK + co);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[i] = *(const u16x8*)(bs + i * 32 * BK + co);
+                for (int i = 0; i < FN; ++i) wf[ks][i] = *(const u16x8*)(bs + i * 32 * BK + co);
+            }
+            // tile kt+1 must have landed before the odd->even barrier (B: end of its memory segment,
+            // A: end of its MFMA segment); one younger tile (kt+2) may stay in flight
+            const bool more = kt + 2 < nkt;
+            if (grpB) { if (more) wait_vm<PW>(); else wait_vm<0>(); }
+            wait_lds_then_barrier();
+            // ---- MFMA segment
+            PCDM_SETPRIO(1);
 #pragma unroll
-            for (int i = 0; i < FN; ++i)
+            for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = mfma_32x32x16(wf[i], xf[j], acc[i][j]);
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = mfma_32x32x16(wf[ks][i], xf[ks][j], acc[i][j]);
+            PCDM_SETPRIO(0);
+            if (!grpB) { if (more) wait_vm<PW>(); else wait_vm<0>(); }
+            wait_lds_then_barrier();
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
-        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        if (!grpB) wait_lds_then_barrier();   // matches group B's leading barrier
+    } else {
+    #pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < nkt) issue_tile(s, s);
+        int cur = 0, nxt = D % STAGES;  // stage of tile kt / of tile kt+D
+        for (int kt = 0; kt < nkt; ++kt) {
+            // tile kt must have landed; up to D-1 younger tiles stay in flight across the barrier
+            const int pending = (nkt - 1 - kt) < (D - 1) ? (nkt - 1 - kt) : (D - 1);
+            if (D >= 3 && pending == 2) wait_vm_then_barrier<2 * (AI + BI)>();
+            else if (D >= 2 && pending == 1) wait_vm_then_barrier<AI + BI>();
+            else wait_vm_then_barrier<0>();
+            // every wave is past its reads of the stage tile kt+D goes to (it held tile kt-1)
+            if (kt + D < nkt && !(p.debug & 1)) issue_tile(kt + D, nxt);
+            const u16* as = As + cur * BM * BK + (wm * WM + frow) * BK;
+            const u16* bs = Bs + cur * BN * BK + (wn * WN + frow) * BK;
+            if (!(p.debug & 2)) {
+                // register double-buffered fragments: the ds_reads of k-step ks+1 are issued BEFORE the MFMAs of
+                // k-step ks (pinned with a scheduling barrier) so they get the whole MFMA window to return
+                u16x8 xf[2][FM], wf[2][FN];
+                auto load_frags = [&](int ks, int b) {
+                    const int co = ((ks * 2 + fhalf) ^ fsw) * 8;
+    #pragma unroll
+                    for (int j = 0; j < FM; ++j) xf[b][j] = *(const u16x8*)(as + j * 32 * BK + co);
+    #pragma unroll
+                    for (int i = 0; i < FN; ++i) wf[b][i] = *(const u16x8*)(bs + i * 32 * BK + co);
+                };
+                load_frags(0, 0);
+    #pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
+                    PCDM_SCHED_BARRIER();
+    #pragma unroll
+                    for (int i = 0; i < FN; ++i)
+    #pragma unroll
+                        for (int j = 0; j < FM; ++j) acc[i][j] = mfma_32x32x16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j]);
+                    PCDM_SCHED_BARRIER();
+                }
+            }
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        }
     }
 
     // ---- epilogue: lane holds, per (fn, fm, quad), channels n..n+3 of row m
@@ -315,19 +410,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = STAGES * (BM + BN) * BK * (int)sizeof(u16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV>,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     GemmArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = a.Npad / BN;
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV>), dim3(g.tiles_m * g.tiles_n * g.split_k),
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG>), dim3(g.tiles_m * g.tiles_n * g.split_k),
                 dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
     if (g.split_k > 1) {
@@ -354,6 +449,8 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         case 8: return launch_gemm<64, 64, 2, 2, 4, CONV>(a, st);     // 4 waves,  64 KiB, 2 blocks / CU
         case 9: return launch_gemm<256, 128, 4, 2, 2, CONV>(a, st);   // 8 waves,  96 KiB, 1 block / CU
         case 10: return launch_gemm<128, 64, 2, 2, 3, CONV>(a, st);   // 4 waves,  72 KiB, 2 blocks / CU
+        case 11: return launch_gemm<256, 128, 4, 2, 3, CONV, true>(a, st);  // as 1, staggered wave groups
+        case 12: return launch_gemm<256, 64, 4, 2, 3, CONV, true>(a, st);   // as 6, staggered wave groups
         default: return -1;
     }
 }
@@ -363,6 +460,11 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (!p || !p->a || !p->w || !p->out) return -1;
     if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->K % BK || p->Npad % 64 || p->Npad < p->N || p->N % 4) return -1;
     if (p->rows_per_batch <= 0) return -1;
+    // 32-bit buffer offsets: every operand must stay below 2 GiB
+    const int64_t lim = 0x7fffffffLL;
+    if ((int64_t)p->Npad * p->K * 2 >= lim) return -2;
+    if (p->conv ? ((int64_t)p->B * p->Hi * p->Wi * p->cin * 2 + ((int64_t)p->Wi + 1) * p->cin * 2 >= lim)
+                : ((int64_t)p->M * p->lda * 2 >= lim || (p->a2 && (int64_t)p->M * p->lda2 * 2 >= lim))) return -2;
     GemmArgs a;
     a.a = (const u16*)p->a;
     a.a2 = (const u16*)p->a2;
@@ -406,7 +508,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     hipStream_t st = (hipStream_t)s;
     int tile = p->tile & 0xff;
     const bool n128 = p->Npad % 128 == 0;
-    const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9;
+    const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11;
     if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128) return -1;  // GEGLU pairs need a 64-wide wave tile
     if (tile == 0) {
         const int64_t t256 = (int64_t)((p->M + 255) / 256) * (p->Npad / 128);

@@ -4,8 +4,8 @@
 // fixed 8-channel octet (16-byte loads/stores, cdna_hip_programming.md G13) and walks rows, which
 // keeps per-channel accumulators / affine coefficients in registers; a row of C channels is read by
 // C/8 consecutive lanes (fully coalesced).  Reductions: registers -> LDS across row-lanes ->
-// fp32 per-(chunk,channel) partials -> one wave per (batch, group) finishes in fp64 with
-// __shfl_xor (wave = 64).  The GroupNorm input may be the virtual concat of two tensors so the
+// per-channel sums in LDS -> fp32 per-(chunk, group) partials; the apply kernel's prologue finishes them in
+// fp64 (fixed order, deterministic), so a GroupNorm is two launches.  The GroupNorm input may be the virtual concat of two tensors so the
 // up-block skip concat (ref stage2_inpaint_unet_2d_condition.py:792-793) is never materialised
 // on the input side.
 #include "pcdm_device.h"
@@ -13,6 +13,7 @@
 
 namespace {
 constexpr int kGnMaxChunks = 64;
+constexpr int kGnMaxC = 4096;
 constexpr int kThreads = 256;
 
 struct GnGeom {
@@ -31,11 +32,12 @@ __device__ __forceinline__ u16x8 gn_load(const u16* x1, int C1, const u16* x2, i
     return *(const u16x8*)p;
 }
 
-// part: [B][nchunk][2][C]  (plane 0 = sum, plane 1 = sum of squares)
+// part: [B][nchunk][groups][2]  per-(row-chunk, group) partial {sum, sum of squares}, fixed summation order
 __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restrict__ x1, int C1,
                                                           const u16* __restrict__ x2, int C2, int HW,
-                                                          int rows_per_chunk, float* __restrict__ part) {
+                                                          int rows_per_chunk, int groups, float* __restrict__ part) {
     __shared__ float red[kThreads * 16];
+    __shared__ float chs[kGnMaxC], chq[kGnMaxC];   // per-channel sums of this block's row chunk
     const int C = C1 + C2;
     const GnGeom g = gn_geom(C);
     const int t = threadIdx.x;
@@ -68,7 +70,6 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restric
         }
         __syncthreads();
         if (rp == 0 && oc < g.noct) {
-            float* ps = part + (((int64_t)b * nchunk + chunk) * 2) * C + oc * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float ss = 0.f, qq = 0.f;
@@ -76,65 +77,66 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restric
                     ss += red[(j * g.tpr + oc0) * 16 + e];
                     qq += red[(j * g.tpr + oc0) * 16 + 8 + e];
                 }
-                ps[e] = ss;
-                ps[C + e] = qq;
+                chs[oc * 8 + e] = ss;
+                chq[oc * 8 + e] = qq;
             }
         }
     }
-}
-
-// one wave per (b, group): stats[b][g] = {mean, rstd}
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int C,
-                                                        int groups, int HW, float eps, float* __restrict__ stats) {
-    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    __syncthreads();
     const int gs = C / groups;
-    const int lane = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    const int n = nchunk * gs;
-    for (int i = lane; i < n; i += 64) {
-        const int ch = i / gs, c = g * gs + (i - ch * gs);
-        const float* ps = part + (((int64_t)b * nchunk + ch) * 2) * C + c;
-        s += (double)ps[0];
-        q += (double)ps[C];
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        s += __shfl_xor(s, m, 64);
-        q += __shfl_xor(q, m, 64);
-    }
-    if (lane == 0) {
-        const double cnt = (double)HW * gs;
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[(b * groups + g) * 2 + 0] = (float)mean;
-        stats[(b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int grp = t; grp < groups; grp += kThreads) {
+        float ss = 0.f, qq = 0.f;
+        for (int c = grp * gs; c < (grp + 1) * gs; ++c) {
+            ss += chs[c];
+            qq += chq[c];
+        }
+        float* ps = part + (((int64_t)b * nchunk + chunk) * groups + grp) * 2;
+        ps[0] = ss;
+        ps[1] = qq;
     }
 }
 
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restrict__ x1, int C1,
                                                           const u16* __restrict__ x2, int C2, int HW,
-                                                          int rows_per_chunk, int groups,
-                                                          const float* __restrict__ stats,
+                                                          int rows_per_chunk, int groups, float eps,
+                                                          const float* __restrict__ part,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int fuse_silu,
                                                           u16* __restrict__ y) {
+    __shared__ float stat[2 * 256];  // {mean, rstd} per group of this batch row
     const int C = C1 + C2;
     const GnGeom g = gn_geom(C);
     const int t = threadIdx.x;
     const int rp = t / g.tpr, oc0 = t - rp * g.tpr;
+    const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+    const int gs = C / groups;
+    // finish the statistics (every block of batch row b redoes this tiny reduction: groups x nchunk x 2 floats,
+    // fp64, fixed order -> bit-identical in every block and run to run; saves a launch per GroupNorm)
+    for (int grp = t; grp < groups; grp += kThreads) {
+        double s = 0.0, q = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float* ps = part + (((int64_t)b * nchunk + ch) * groups + grp) * 2;
+            s += (double)ps[0];
+            q += (double)ps[1];
+        }
+        const double cnt = (double)HW * gs;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[2 * grp] = (float)mean;
+        stat[2 * grp + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
     if (rp >= g.rows_par) return;
-    const int chunk = blockIdx.x, b = blockIdx.y;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = (r0 + rows_per_chunk < HW) ? r0 + rows_per_chunk : HW;
-    const int gs = C / groups;
     for (int oc = oc0; oc < g.noct; oc += g.tpr) {
         float sc[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = oc * 8 + e;
             const int grp = c / gs;
-            const float mean = stats[(b * groups + grp) * 2], rstd = stats[(b * groups + grp) * 2 + 1];
+            const float mean = stat[2 * grp], rstd = stat[2 * grp + 1];
             sc[e] = rstd * gamma[c];
             sh[e] = beta[c] - mean * sc[e];
         }
@@ -221,29 +223,25 @@ inline int gn_chunks(int HW, int rows_par) {
 }  // namespace
 
 extern "C" int64_t pcdm_groupnorm_ws_floats(int B, int C) {
-    return (int64_t)B * kGnMaxChunks * 2 * C + (int64_t)B * 2 * C;
+    (void)C;
+    return (int64_t)B * kGnMaxChunks * 256 * 2;   // [B][chunks][groups <= 256][2]
 }
 
 extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
                               const float* gamma, const float* beta, int fuse_silu, void* y, float* ws,
                               pcdm_stream_t s) {
     const int C = C1 + C2;
-    if (!x1 || !y || !ws || B <= 0 || HW <= 0 || groups <= 0) return -1;
-    if (C1 % 8 || C2 % 8 || C % groups || C > 4096 || (C2 > 0 && !x2)) return -1;
+    if (!x1 || !y || !ws || B <= 0 || HW <= 0 || groups <= 0 || groups > 256) return -1;
+    if (C1 % 8 || C2 % 8 || C % groups || C > kGnMaxC || (C2 > 0 && !x2)) return -1;
     hipStream_t st = (hipStream_t)s;
     const GnGeom g = gn_geom(C);
     const int nchunk = gn_chunks(HW, g.rows_par);
     const int rpc = (HW + nchunk - 1) / nchunk;
-    float* part = ws;
-    float* stats = ws + (int64_t)B * kGnMaxChunks * 2 * C;
     PCDM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, (const u16*)x1, C1, (const u16*)x2, C2, HW,
-                rpc, part);
-    PCDM_CHECK_LAUNCH();
-    PCDM_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, (const float*)part, nchunk, C, groups, HW, eps,
-                stats);
+                rpc, groups, ws);
     PCDM_CHECK_LAUNCH();
     PCDM_LAUNCH(gn_apply_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, (const u16*)x1, C1, (const u16*)x2, C2, HW,
-                rpc, groups, (const float*)stats, gamma, beta, fuse_silu, (u16*)y);
+                rpc, groups, eps, (const float*)ws, gamma, beta, fuse_silu, (u16*)y);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

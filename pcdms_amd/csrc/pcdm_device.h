@@ -69,6 +69,35 @@ __device__ __forceinline__ void glds_wait() {
 #endif
 }
 
+// ---- LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds) ------------------------
+// address = base + voff (per lane, VGPR) + soff (wave-uniform, SGPR); lanes whose voff has bit 31 set are out
+// of range: the hardware bounds check makes them deliver ZEROS (no branch, no separate zero source).
+#ifdef PCDM_EMU
+struct BufRsrc { const char* base; };
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p) { return BufRsrc{(const char*)p}; }
+__device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    char* d = (char*)lds_wave_base + 16 * emu::lane_id();
+    if (voff & 0x80000000u) memset(d, 0, 16);
+    else memcpy(d, r.base + voff + soff, 16);
+}
+#else
+struct BufRsrc { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p) {
+    return BufRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)};
+}
+__device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+#endif
+
+#ifdef PCDM_EMU
+#define PCDM_SCHED_BARRIER() ((void)0)
+#define PCDM_SETPRIO(n) ((void)0)
+#else
+#define PCDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define PCDM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // ---- math ----------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_exp2(float x) {
 #ifdef PCDM_EMU

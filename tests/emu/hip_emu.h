@@ -46,6 +46,7 @@ int lane_id();
 #define __restrict__
 inline void __syncthreads() { emu::syncthreads(); }
 inline float __expf(float x) { return expf(x); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -35,14 +35,14 @@ def main():
         a = torch.randn(M, K, device=dev).to(BF16)
         pw = ops.pack_linear(torch.randn(N, K) / math.sqrt(K), torch.randn(N), dev)
         out = torch.empty(M, N, dtype=BF16, device=dev)
-        tiles = [t for t in (1, 4, 3, 2) if not (t in (1, 4) and pw.Npad % 128)]
+        tiles = [t for t in (1, 11, 4, 6, 12, 3) if not (t in (1, 4, 11) and pw.Npad % 128)]
         run(f"linear M{M} K{K} N{N}", lambda tl: ops.gemm(a, pw, out, tile=tl), 2.0 * M * K * N, tiles)
     for (H, W, Ci, Co) in [(32, 44, 1920, 640), (64, 88, 640, 320), (16, 22, 1280, 1280)]:
         x = torch.randn(B, H, W, Ci, device=dev).to(BF16)
         pw = ops.pack_conv3x3(torch.randn(Co, Ci, 3, 3) / math.sqrt(9 * Ci), torch.randn(Co), dev)
         out = torch.empty(B * H * W, Co, dtype=BF16, device=dev)
         cv = dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W)
-        tiles = [t for t in (1, 4, 3, 2) if not (t in (1, 4) and pw.Npad % 128)]
+        tiles = [t for t in (1, 11, 4, 6, 12, 3) if not (t in (1, 4, 11) and pw.Npad % 128)]
         run(f"conv3x3 {Ci}->{Co} @{H}x{W}", lambda tl: ops.gemm(x, pw, out, conv=cv, tile=tl), 2.0 * B * H * W * Co * 9 * Ci, tiles)
 
 
