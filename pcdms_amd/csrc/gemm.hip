@@ -315,6 +315,79 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         }
         return;
     }
+    // ---- LDS-staged epilogue (STORE / GEGLU): the accumulator quads (4 channels x 32 rows per instruction, i.e.
+    // 16-byte pieces of 32 different 128-byte lines) go through a wave-private fp32 LDS tile and come back
+    // row-major, so that every global access of the epilogue is a full 16 B per lane / whole 128-byte lines:
+    // residual loads and bf16 stores.  Measured on the thin-K linears (K = 320): the direct quad stores
+    // sustained only ~1.4 TB/s.  Single rounding is preserved (fp32 until the final convert).
+    if ((p.epilogue == PCDM_EPI_STORE || (p.epilogue == PCDM_EPI_GEGLU && FN == 2)) && (p.N & 7) == 0 && (p.ldo & 7) == 0 &&
+        (!p.residual || (p.ldr & 7) == 0)) {
+        const bool geglu = p.epilogue == PCDM_EPI_GEGLU;
+        constexpr int EPW = WN + 4;                       // fp32 row pitch (conflict-free ds_write_b128)
+        __syncthreads();                                  // every wave is done with the operand stages
+        float* ep = (float*)smem + wave * (32 * EPW);     // wave-private 32 x WN tile
+        const int wno = geglu ? WN / 2 : WN;              // output columns of this wave
+        const int lpr = wno / 8;                          // lanes per output row (16 B each)
+        const int rpi = 64 / lpr;                         // rows per store instruction
+        const int ncol0 = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            // 1. quads -> LDS [row = pixel (lane&31)][col = channel]
+            if (geglu) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int nl = 8 * rg + 4 * half;
+                    const f32x4 bh = *(const f32x4*)(p.bias + n0 + wn * WN + nl);
+                    const f32x4 bg = *(const f32x4*)(p.bias + n0 + wn * WN + nl + 32);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (acc[0][j][4 * rg + e] + bh[e]) * gelu_erf_f(acc[FN - 1][j][4 * rg + e] + bg[e]);
+                    *(f32x4*)(ep + (lane & 31) * EPW + nl) = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const f32x4 v = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+                        *(f32x4*)(ep + (lane & 31) * EPW + i * 32 + 8 * rg + 4 * half) = v;
+                    }
+            }
+            PCDM_WAVE_SYNC();
+            // 2. row-major read-back (same wave: LDS ops complete in order), fused epilogue, 16-byte stores
+            for (int r0 = 0; r0 < 32; r0 += rpi) {
+                const int r = r0 + lane / lpr, c8 = (lane % lpr) * 8;
+                const int m = m0 + wm * WM + j * 32 + r, n = ncol0 + c8;
+                if (r < 32 && m < p.M && n < p.N) {
+                    const f32x4 v0 = *(const f32x4*)(ep + r * EPW + c8), v1 = *(const f32x4*)(ep + r * EPW + c8 + 4);
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (!geglu && p.bias) {
+                        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
+                    }
+                    if (p.rowvec) {
+                        const float* tv = p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n;
+                        const f32x4 t0 = *(const f32x4*)tv, t1 = *(const f32x4*)(tv + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[e + 4] += t1[e]; }
+                    }
+                    if (p.residual) {
+                        const u16x8 rv = *(const u16x8*)(p.residual + (int64_t)(m % p.res_mod) * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+                    }
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+                    *(u16x8*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
+                }
+            }
+            PCDM_WAVE_SYNC();   // pass j's reads precede pass j+1's writes
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = m0 + wm * WM + j * 32 + (lane & 31);

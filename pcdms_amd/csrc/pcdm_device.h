@@ -93,7 +93,10 @@ __device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t so
 #ifdef PCDM_EMU
 #define PCDM_SCHED_BARRIER() ((void)0)
 #define PCDM_SETPRIO(n) ((void)0)
+// lanes of a wave run in lockstep on the GPU; the emulator's fibers need an explicit rendezvous
+#define PCDM_WAVE_SYNC() ((void)__shfl_xor(0, 1, 64))
 #else
+#define PCDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define PCDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define PCDM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
