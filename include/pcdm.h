@@ -94,7 +94,7 @@ int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, cons
  * pcdm_timestep_embedding: diffusers Timesteps(dim, flip_sin_to_cos, shift) (ref :184,677): out fp32 [B,dim];
  *   t read from DEVICE memory: t_dev[step_dev ? *step_dev : 0] (int64), broadcast over B.
  * pcdm_small_linear: y[b,n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), x,y fp32, W bf16 [N,K],
- *   B <= 32; act flags: 1 = SiLU.  (TimestepEmbedding MLPs ref :191-197,247; every ResnetBlock2D.time_emb_proj) */
+ *   B <= 32; act_in: 1 = SiLU; act_out: 1 = SiLU before `add`, 2 = SiLU after `add`.  (TimestepEmbedding MLPs ref :191-197,247; every ResnetBlock2D.time_emb_proj) */
 int pcdm_timestep_embedding(const int64_t* t_dev, const int32_t* step_dev, float* out, int B, int dim,
                             int flip_sin_to_cos, float shift, pcdm_stream_t s);
 int pcdm_small_linear(const float* x, const void* w, const float* bias, const float* add, float* y, int B, int K,

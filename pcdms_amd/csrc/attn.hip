@@ -3,8 +3,9 @@
 // (stage2_batchtest_inpaint_model.py:133): o = softmax(q k^T * scale) v, fp32 softmax, no mask.
 //
 // Design (wave = 64, v_mfma_f32_32x32x16_bf16):
-//  * workgroup = 4 waves; each wave owns 32 query rows and the whole head_dim; K / V^T tiles of
-//    64 keys are register-staged into double-buffered LDS by all 256 threads (one barrier per tile).
+//  * workgroup = 4 waves; each wave owns 32 query rows and the whole head_dim; K / V^T tiles of 64 keys go
+//    HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds: constant per-lane offsets + a wave-uniform SGPR offset per
+//    tile, out-of-range keys zero-filled by the hardware bounds check), double-buffered, one barrier per tile.
 //  * QK^T is issued "swapped": S^T = K * Q^T, so a lane holds 32 scores of ONE query (the other 32
 //    live in lane^32).  Row max / row sum are 31 in-register ops + one __shfl_xor(.,32); the online
 //    softmax rescale of O^T is lane-uniform.  No serial-lane softmax, no LDS round trip for P.
@@ -15,13 +16,12 @@
 //  * V is consumed as V^T [d][key] (key contiguous): the projection GEMM writes it transposed
 //    (PCDM_EPI_SPLIT_VT), so the A operand of the PV MFMA is a plain ds_read_b128 -- no transpose
 //    anywhere in this kernel.
-//  * LDS rows padded 64 -> 72 bf16 (conflict-free ds_read_b128 / ds_write_b128, see gemm.hip).
+//  * LDS rows are unpadded and XOR-swizzled (conflict-free ds_read_b128, see gemm.hip).
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 
 namespace {
 constexpr int KB = 64;     // keys per tile
-constexpr int LDSK = 72;   // padded LDS row (bf16)
 constexpr int QPW = 32;    // queries per wave
 constexpr int QPB = 128;   // queries per workgroup
 
@@ -30,9 +30,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
                                                          const u16* __restrict__ vt, int64_t ldvt,
                                                          u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
                                                          float c /* scale * log2(e) */) {
-    __shared__ __attribute__((aligned(16))) u16 Ks[2][KB][LDSK];
-    __shared__ __attribute__((aligned(16))) u16 Vs[2][64][LDSK];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // K tile [64 keys][64 d] and V^T tile [64 d][64 keys], 2 stages each, unpadded 128-byte rows whose 16-byte
+    // chunks are XOR-swizzled by (row>>1)&7 (applied on the DMA source offset and on the fragment reads, exactly
+    // as in gemm.hip): conflict-free ds_read_b128, filled by buffer_load ... lds with no VGPR round trip.
+    // (ONE __shared__ object: with a second one hipcc drains vmcnt before the first ds_read after a DMA issue)
+    __shared__ __attribute__((aligned(16))) u16 KV[2][2][KB * 64];   // [stage][K | V^T][row * 64 + col]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * QPB + wave * QPW;
     const int hh = lane >> 5, col = lane & 31;
@@ -46,28 +50,29 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u16x8*)(qp + ks * 16);
 
-    // staging coordinates: 2 chunks of K and 2 chunks of V^T per thread
-    const int cc = t & 7, rr = t >> 3;
-    const u16* kbase = k + (int64_t)b * Lk * ldk + h * 64 + cc * 8;
-    const u16* vbase = vt + ((int64_t)(b * H + h) * 64) * ldvt + cc * 8;
-    u16x8 rk[2], rv[2];
-    auto load_tile = [&](int key0) {
+    // LDS-DMA staging: wave w, instruction j fills rows (2w+j)*8 .. +7 of the K tile and of the V^T tile
+    constexpr uint32_t kOOB = 0x80000000u;
+    const int srow = lane >> 3, spos = lane & 7;
+    const BufRsrc rs_k = make_buf_rsrc(k + (int64_t)b * Lk * ldk + h * 64);
+    const BufRsrc rs_v = make_buf_rsrc(vt + ((int64_t)(b * H + h) * 64) * ldvt);
+    uint32_t k_off[2], v_off[2];
+    int v_chunk[2], k_row[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = key0 + rr + 32 * i;
-            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (key < Lk) v = *(const u16x8*)(kbase + (int64_t)key * ldk);
-            rk[i] = v;
-            u16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (key0 + cc * 8 < ldvt) w = *(const u16x8*)(vbase + (int64_t)(rr + 32 * i) * ldvt + key0);
-            rv[i] = w;
-        }
-    };
-    auto store_tile = [&](int buf) {
+    for (int j = 0; j < 2; ++j) {
+        const int rl = (wave * 2 + j) * 8 + srow;          // tile row: key (K) / d (V^T)
+        const int gch = spos ^ ((rl >> 1) & 7);            // global 16-byte chunk stored at position spos
+        k_row[j] = rl;
+        k_off[j] = (uint32_t)((int64_t)rl * ldk * 2) + gch * 16u;
+        v_off[j] = (uint32_t)((int64_t)rl * ldvt * 2) + gch * 16u;
+        v_chunk[j] = gch * 8;
+    }
+    auto issue_tile = [&](int key0, int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(u16x8*)&Ks[buf][rr + 32 * i][cc * 8] = rk[i];
-            *(u16x8*)&Vs[buf][rr + 32 * i][cc * 8] = rv[i];
+        for (int j = 0; j < 2; ++j) {
+            buf_glds16(rs_k, key0 + k_row[j] < Lk ? k_off[j] : kOOB, (uint32_t)((int64_t)key0 * ldk * 2),
+                       &KV[buf][0][(wave * 2 + j) * 8 * 64]);
+            buf_glds16(rs_v, key0 + v_chunk[j] < ldvt ? v_off[j] : kOOB, (uint32_t)(key0 * 2),
+                       &KV[buf][1][(wave * 2 + j) * 8 * 64]);
         }
     };
 
@@ -77,13 +82,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
     float m_run = -1e30f, l_run = 0.f;
 
     const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);  // K row permutation
+    const int sw_k = (pi >> 1) & 7, sw_v = (col >> 1) & 7;             // fragment-read swizzles (rows 32-aligned)
     const int nkb = (Lk + KB - 1) / KB;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    issue_tile(0, 0);
     for (int kb = 0; kb < nkb; ++kb) {
         const int cur = kb & 1, key0 = kb * KB;
-        if (kb + 1 < nkb) load_tile(key0 + KB);
+        glds_wait();       // this wave's DMAs of tile kb have landed ...
+        __syncthreads();   // ... everybody's have; and everybody is done reading buffer cur^1
+        if (kb + 1 < nkb) issue_tile(key0 + KB, cur ^ 1);
 
         // ---- S^T = K Q^T  (two 32-key fragments)
         f32x16 s[2];
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf) {
-                const u16x8 kfrag = *(const u16x8*)&Ks[cur][kf * 32 + pi][ks * 16 + hh * 8];
+                const u16x8 kfrag = *(const u16x8*)&KV[cur][0][(kf * 32 + pi) * 64 + (((ks * 2 + hh) ^ sw_k) * 8)];
                 s[kf] = mfma_32x32x16(kfrag, qf[ks], s[kf]);
             }
         }
@@ -137,12 +143,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
         for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
             for (int df = 0; df < 2; ++df) {
-                const u16x8 vfrag = *(const u16x8*)&Vs[cur][df * 32 + col][s4 * 16 + hh * 8];
+                const u16x8 vfrag = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
                 oacc[df] = mfma_32x32x16(vfrag, pf[s4], oacc[df]);
             }
         }
-        if (kb + 1 < nkb) store_tile(cur ^ 1);
-        __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -165,6 +169,7 @@ extern "C" int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_
                                void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, pcdm_stream_t s) {
     if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
     if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < Lk) return -1;
+    if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
     PCDM_LAUNCH(flash_attn_kernel, grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
                 (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f);

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
             const float s = wave_sum(acc[i]);
             if (lane == 0 && valid && b0 + i < B) {
                 float v = s + (bias ? bias[n] : 0.f);
-                if (act_out) v = silu_f(v);
+                if (act_out == 1) v = silu_f(v);
                 if (add) v += add[(int64_t)(b0 + i) * N + n];
+                if (act_out == 2) v = silu_f(v);   // activation of the SUM (emb = time + class, consumed as silu(emb))
                 y[(int64_t)(b0 + i) * N + n] = v;
             }
         }

@@ -52,14 +52,23 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         if (active && oc < g.noct) {
-            for (int r = r0 + rp; r < r1; r += g.rows_par) {
-                const u16x8 v = gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, oc * 8);
+            // 4 independent 16-byte loads in flight per thread (the loop is HBM-latency bound otherwise)
+            for (int r = r0 + rp; r < r1; r += 4 * g.rows_par) {
+                u16x8 v[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = bf2f(v[e]);
-                    s[e] += f;
-                    q[e] += f * f;
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + u * g.rows_par;
+                    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    v[u] = rr < r1 ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + rr, oc * 8) : z;
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = bf2f(v[u][e]);
+                        s[e] += f;
+                        q[e] += f * f;
+                    }
             }
         }
         __syncthreads();  // previous iteration's readers are done with `red`
@@ -140,17 +149,26 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
             sc[e] = rstd * gamma[c];
             sh[e] = beta[c] - mean * sc[e];
         }
-        for (int r = r0 + rp; r < r1; r += g.rows_par) {
-            const int64_t row = (int64_t)b * HW + r;
-            const u16x8 v = gn_load(x1, C1, x2, C2, row, oc * 8);
-            u16x8 o;
+        for (int r = r0 + rp; r < r1; r += 4 * g.rows_par) {
+            u16x8 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf2f(v[e]) * sc[e] + sh[e];
-                if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
-                o[e] = f2bf(f);
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * g.rows_par;
+                if (rr < r1) v[u] = gn_load(x1, C1, x2, C2, (int64_t)b * HW + rr, oc * 8);
             }
-            *(u16x8*)(y + row * C + oc * 8) = o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * g.rows_par;
+                if (rr >= r1) break;
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(v[u][e]) * sc[e] + sh[e];
+                    if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
+                    o[e] = f2bf(f);
+                }
+                *(u16x8*)(y + ((int64_t)b * HW + rr) * C + oc * 8) = o;
+            }
         }
     }
 }

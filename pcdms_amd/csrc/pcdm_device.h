@@ -118,7 +118,15 @@ __device__ __forceinline__ float fast_rcp(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf-based GELU (PyTorch F.gelu default, diffusers GEGLU)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 rounding of the result): one v_exp,
+// one v_rcp and a 5-term Horner -- ~3x fewer instructions than libm erff, which dominated the GEGLU epilogue.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * fast_exp2(-1.44269504088896341f * z * z);   // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
+}
 
 // ---- MFMA (cdna_hip_programming.md §3 fragment maps) -----------------------------------------
 // 32x32x16 bf16:  A lane l -> row  (l&31), k = 8*(l>>5)+e ;  B lane l -> col (l&31), same k ;

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Union
 
 import torch
 
@@ -290,8 +290,8 @@ def timestep_embedding(t_dev: torch.Tensor, step_dev: Optional[torch.Tensor], ou
 
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
-                 add: Optional[torch.Tensor] = None, act_in: bool = False, act_out: bool = False) -> torch.Tensor:
-    """x fp32 [B,K], w bf16 [N,K] -> out fp32 [B,N]."""
+                 add: Optional[torch.Tensor] = None, act_in: bool = False, act_out: Union[bool, int] = False) -> torch.Tensor:
+    """x fp32 [B,K], w bf16 [N,K] -> out fp32 [B,N].  act_out: True/1 = SiLU before ``add``, 2 = SiLU after it."""
     _c(x, torch.float32); _c(w, BF16); _c(out, torch.float32)
     B, K = x.shape
     N = w.shape[0]

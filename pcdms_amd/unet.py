@@ -417,9 +417,11 @@ class Stage2_InapintUNet2DConditionModel:
                                            self._buf("cls2", (B, temb_dim), torch.float32))
                 self._store("cls", class_labels, cls_emb)
         e1 = ops.small_linear(t_emb, W["time1"][0], W["time1"][1], self._buf("e1", (B, temb_dim), torch.float32), act_out=True)
-        emb = ops.small_linear(e1, W["time2"][0], W["time2"][1], self._buf("emb", (B, temb_dim), torch.float32), add=cls_emb)
+        # emb = time_emb + class_emb is only ever consumed as silu(emb) (ResnetBlock2D): apply it here, once
+        emb_act = ops.small_linear(e1, W["time2"][0], W["time2"][1], self._buf("emb", (B, temb_dim), torch.float32),
+                                   add=cls_emb, act_out=2 if cls_emb is not None else 1)
         # every ResnetBlock2D.time_emb_proj(silu(emb)) in one launch
-        temb = ops.small_linear(emb, W["temb_w"], W["temb_b"], self._buf("temb", (B, W["temb_n"]), torch.float32), act_in=True)
+        temb = ops.small_linear(emb_act, W["temb_w"], W["temb_b"], self._buf("temb", (B, W["temb_n"]), torch.float32))
 
         # ---- step-invariant conditioning (Appendix C-5), cached on tensor identity
         pose_nhwc = self._cached("pose", pose)
