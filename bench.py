@@ -55,7 +55,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PCDM_BENCH_FORCE_DIST") == "1"   # (1-rank RCCL group: test hook)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
@@ -98,27 +99,27 @@ def main():
                     guidance_scale=2.0, num_inference_steps=args.ddim_steps, output_type="latent",
                     use_graph=not args.no_graph).latents
 
-    gathered = torch.empty(world * N, 4, h, w, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty(world * N, 4, h, w, dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         lat = one_call(dinp["latents"])
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, lat)   # the single collective of the path (RCCL over xGMI)
         return lat
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -143,7 +144,7 @@ def main():
         result["roofline"] = kernel_roofline(pipe, ops, dinp, N, h, w)
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, cfg, inp, N, args.ddim_steps)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -168,15 +169,19 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
     tiles = {}
     for name, flops, e0, e1, info in log:
         if name == "gemm_kernel":
-            tiles[info[-1]] = tiles.get(info[-1], 0) + 1
+            tiles[info[-2]] = tiles.get(info[-2], 0) + 1
         f = fam.setdefault(name, [0, 0.0, 0.0])
         f[0] += 1
         f[1] += flops
         f[2] += e0.elapsed_time(e1) * 1e-3
     gk = fam["gemm_kernel"]
     achieved = gk[1] / gk[2] / 1e12
+    traffic = None
+    tj = ROOT / "profiles" / "gemm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (offline; see file)
+    if tj.exists():
+        traffic = json.loads(tj.read_text()).get("hbm_bytes_per_launch")
     out = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+           "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
            "kernel": "gemm_kernel<BM,BN,CONV> (implicit-GEMM conv3x3 + linear, all instances)",
            "launches_per_denoise_step": gk[0], "avg_launch_us": round(gk[2] / gk[0] * 1e6, 2),
            "alg_gflop_per_launch": round(gk[1] / gk[0] / 1e9, 2),

@@ -233,7 +233,8 @@ class Stage2_InpaintDiffusionPipeline:
                 st["lat"].copy_(lat0)
                 st["step"].zero_()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime while we capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._step_eager(st)
                 st["lat"].copy_(lat0)
                 st["step"].zero_()
