@@ -1,0 +1,45 @@
+"""Measure the best (tile configuration, split-K) of gemm.hip for every GEMM / conv problem shape of the stage-2
+UNet on this MI355X and write pcdms_amd/tuning/gfx950.json (committed; shapes outside it are tuned online).
+
+    python tools/tune_gemm_shapes.py [--out gpurun_out/gfx950.json]
+Shapes covered: latent 64x88 (352x512 pairs) at UNet batch 8 and 16 (configs[1], configs[2]) and latent 32x64
+(256x256 pairs, configs[0]) at UNet batch 2 and 8.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    from oracle.unet import UNetConfig, synth_state_dict
+    from pcdms_amd import ops
+    from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
+    from tests.test_unet import _inputs, _kwargs
+    ops._TUNED.clear()
+    ops.TUNE_ITERS, ops.TUNE_REPEATS = 5, 3
+    dev = torch.device("cuda:0")
+    cfg = UNetConfig()
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(synth_state_dict(cfg, seed=0))
+    m.to(dev)
+    for (B, h, w) in [(8, 64, 88), (16, 64, 88), (2, 32, 64), (8, 32, 64)]:
+        s, e, c, p = _inputs(cfg, B, h, w, 258)
+        m(s.to(dev), torch.tensor(500, device=dev), e.to(dev), class_labels=c.to(dev), my_pose_cond=p.to(dev))
+        torch.cuda.synchronize()
+        print(f"B={B} latent {h}x{w}: {len(ops._TUNED)} shapes tuned", flush=True)
+    out = Path(args.out) if args.out else ops.TUNING_FILE
+    ops.save_tuning(out, note=f"MI355X gfx950, torch {torch.__version__}, tools/tune_gemm_shapes.py, best of 3 x 5 launches")
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
