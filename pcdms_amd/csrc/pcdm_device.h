@@ -155,6 +155,32 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(u16x8 a, u16x8 b, f32x16 c) {
 #endif
 }
 
+// ---- inter-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16) ----------------
+#ifdef PCDM_EMU
+__device__ __forceinline__ void pcdm_drain_vmem() {}
+__device__ __forceinline__ void pcdm_release_agent() {}
+__device__ __forceinline__ void pcdm_acquire_agent() {}
+__device__ __forceinline__ unsigned pcdm_atomic_inc_agent(unsigned* p) { return (*p)++; }
+__device__ __forceinline__ float pcdm_load_agent(const float* p) { return *p; }
+__device__ __forceinline__ void pcdm_store_agent(float* p, float v) { *p = v; }
+#else
+__device__ __forceinline__ void pcdm_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pcdm_release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (G16 pitfall 12)
+}
+__device__ __forceinline__ void pcdm_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ unsigned pcdm_atomic_inc_agent(unsigned* p) {
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pcdm_store_agent(float* p, float v) {   // sc1 write-through store
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float pcdm_load_agent(const float* p) {   // L2-served (bypasses this CU's L1)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // ---- wave reductions -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -49,7 +49,7 @@ def _c(t: torch.Tensor, dtype) -> torch.Tensor:
 # ------------------------------------------------------------------------------------ norms
 def groupnorm_ws(B: int, C: int, device) -> torch.Tensor:
     n = _lib.lib().pcdm_groupnorm_ws_floats(B, C)
-    return torch.empty(n, dtype=torch.float32, device=device)
+    return torch.zeros(n, dtype=torch.float32, device=device)   # arrival counters must start at zero
 
 
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,

@@ -449,7 +449,7 @@ class Stage2_InapintUNet2DConditionModel:
         def resnet(p, x1, x2, HW_, hh, ww, name):
             r = W[p]
             cin, cout, M = r["cin"], r["cout"], B * HW_
-            ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32)
+            ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
             cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
             tv = temb[:, r["toff"]: r["toff"] + cout]
@@ -464,7 +464,7 @@ class Stage2_InapintUNet2DConditionModel:
         def transformer(p, x, HW_, name):
             a = W[p]
             c, H, M = a["c"], a["heads"], B * HW_
-            ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32)
+            ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
             t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)))
             # self-attention
@@ -529,7 +529,7 @@ class Stage2_InapintUNet2DConditionModel:
                              conv=dict(B=B, Hi=hh, Wi=ww, Ho=2 * hh, Wo=2 * ww, upsample=1))
                 hh, ww = 2 * hh, 2 * ww
         # ---- 6. post-process (ref :817-820)
-        ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32)
+        ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
         n = ops.groupnorm(x, None, B, HW, G, eps, W["norm_out"][0], W["norm_out"][1], True, self._buf("gn", (B * HW, boc[0])), ws)
         out = self._buf("eps", (B, cfg.out_channels, h, w), torch.float32)
         ops.gemm(n, W["conv_out"], out, conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w), rows_per_batch=HW,
