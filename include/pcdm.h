@@ -117,6 +117,10 @@ int pcdm_f32_to_bf16(const float* x, void* y, int64_t n, pcdm_stream_t s);
  * Optionally writes the guided eps (eps_out) and x0 = c0x*x + c0e*eps is left to the host scheduler. */
 int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x, const float* noise, float* x_prev,
                   float* eps_out, const float* coef, const int32_t* step_dev, int64_t n, pcdm_stream_t s);
+/* rescale_noise_cfg (stage2_inpaint_pipeline.py:52-63): out = gr * cfg * std(text)/std(cfg) + (1-gr) * cfg, per sample
+ * over n = C*H*W elements (unbiased std); cfg_eps / text_eps / out fp32 [N, n]; out may alias cfg_eps. */
+int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_eps, float* out, int N, int64_t n,
+                           float guidance_rescale, pcdm_stream_t s);
 /* y = sum_i c[i] * x_i  (i < nin <= 6), fp32; UniPC predictor/corrector linear combinations. */
 int pcdm_lincomb(float* y, int nin, const float* const* xs, const float* c, int64_t n, pcdm_stream_t s);
 /* *step_dev += 1 */

@@ -58,6 +58,7 @@ _SIGS = {
     "pcdm_f32_to_bf16": ([_P, _P, _L, _P], C.c_int),
     "pcdm_cfg_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
     "pcdm_lincomb": ([_P, _I, C.POINTER(_P), C.POINTER(_F), _L, _P], C.c_int),
+    "pcdm_rescale_noise_cfg": ([_P, _P, _P, _I, _L, _F, _P], C.c_int),
     "pcdm_advance_step": ([_P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)

@@ -154,6 +154,43 @@ __global__ void lincomb_kernel(float* __restrict__ y, int nin, LinArgs a, const 
     y[i] = v;
 }
 
+// rescale_noise_cfg (ref stage2_inpaint_pipeline.py:52-63): per-sample unbiased std of the guided eps and of the
+// conditional eps over all C*H*W elements; out = gr * cfg * (std_text / std_cfg) + (1 - gr) * cfg.
+// One workgroup per sample; fp64 block reduction (wave64 shuffles + LDS).
+__global__ __launch_bounds__(1024) void rescale_cfg_kernel(const float* __restrict__ cfg_eps,
+                                                           const float* __restrict__ text_eps, float* __restrict__ out,
+                                                           int64_t n, float gr) {
+    __shared__ double red[16][4];
+    __shared__ float factor;
+    const float* a = cfg_eps + (int64_t)blockIdx.x * n;
+    const float* b = text_eps + (int64_t)blockIdx.x * n;
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = a[i], y = b[i];
+        s[0] += x; s[1] += x * x; s[2] += y; s[3] += y * y;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s[k] += __shfl_xor(s[k], m, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) red[wave][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4] = {0, 0, 0, 0};
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w)
+            for (int k = 0; k < 4; ++k) t[k] += red[w][k];
+        const double var_c = (t[1] - t[0] * t[0] / (double)n) / (double)(n - 1);
+        const double var_t = (t[3] - t[2] * t[2] / (double)n) / (double)(n - 1);
+        factor = (float)sqrt(var_t / var_c);
+    }
+    __syncthreads();
+    const float f = gr * factor + (1.0f - gr);
+    float* o = out + (int64_t)blockIdx.x * n;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[i] * f;
+}
+
 __global__ void advance_step_kernel(int32_t* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
 }
@@ -239,6 +276,14 @@ extern "C" int pcdm_lincomb(float* y, int nin, const float* const* xs, const flo
         a.c[i] = i < nin ? c[i] : 0.f;
     }
     PCDM_LAUNCH(lincomb_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, y, nin, a, (const float*)nullptr, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_eps, float* out, int N, int64_t n,
+                                      float guidance_rescale, pcdm_stream_t s) {
+    if (!cfg_eps || !text_eps || !out || N <= 0 || n <= 1) return -1;
+    PCDM_LAUNCH(rescale_cfg_kernel, dim3(N), dim3(1024), 0, (hipStream_t)s, cfg_eps, text_eps, out, n, guidance_rescale);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -389,5 +389,14 @@ def lincomb(out: torch.Tensor, xs: Sequence[torch.Tensor], cs: Sequence[float]) 
     return out
 
 
+def rescale_noise_cfg(cfg_eps: torch.Tensor, text_eps: torch.Tensor, out: torch.Tensor, guidance_rescale: float) -> torch.Tensor:
+    """fp32 [N, ...] tensors; per-sample std matching (ref stage2_inpaint_pipeline.py:52-63)."""
+    _c(cfg_eps, torch.float32); _c(text_eps, torch.float32); _c(out, torch.float32)
+    N = cfg_eps.shape[0]
+    _chk(_lib.lib().pcdm_rescale_noise_cfg(_ptr(cfg_eps), _ptr(text_eps), _ptr(out), N, cfg_eps.numel() // N,
+                                           float(guidance_rescale), _stream(out)), "pcdm_rescale_noise_cfg")
+    return out
+
+
 def advance_step(step_dev: torch.Tensor) -> None:
     _chk(_lib.lib().pcdm_advance_step(_ptr(step_dev), _stream(step_dev)), "pcdm_advance_step")

@@ -37,12 +37,17 @@ class Stage2_InpaintDiffusionPipelineOutput:
 
 
 def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
-    """ref :52-63.  Inactive in the reference driver (guidance_rescale=0.0,
-    stage2_batchtest_inpaint_model.py:191); provided for API completeness (tiny per-sample statistics)."""
-    raise NotImplementedError("guidance_rescale > 0 is not on the stage-2 hot path (driver passes 0.0)")
+    """ref :52-63 (inactive in the reference driver, which passes guidance_rescale=0.0,
+    stage2_batchtest_inpaint_model.py:191).  One HIP kernel: per-sample std matching + mix."""
+    a, b = noise_cfg.float().contiguous(), noise_pred_text.float().contiguous()
+    return ops.rescale_noise_cfg(a, b, torch.empty_like(a), guidance_rescale).to(noise_cfg.dtype)
 
 
 class Stage2_InpaintDiffusionPipeline:
+    #: False in ``Simple_Stage2_InpaintDiffusionPipeline`` (ref :544-887): no stage-1 embedding, i.e. no class_labels and
+    #: only the 257 projected source-image tokens as context
+    use_prior_embed = True
+
     def __init__(self, unet: Stage2_InapintUNet2DConditionModel, scheduler, vae=None):
         self.unet = unet
         self.scheduler = scheduler
@@ -107,8 +112,6 @@ class Stage2_InpaintDiffusionPipeline:
         device = self.device
         if height % 8 or width % 8:
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
-        if guidance_rescale > 0.0:
-            rescale_noise_cfg(None, None, guidance_rescale)
         bs, num, _ = s_img_proj_f.shape
         N = num_images_per_prompt
         h, w = height // 8, width // 8
@@ -130,12 +133,19 @@ class Stage2_InpaintDiffusionPipeline:
             else mask.to(**f32).contiguous()
         pose = st_pose_f.to(**f32)
         pose_cond = pose.repeat_interleave(N, 0).repeat(rep, 1, 1, 1).contiguous() if bs > 1 else pose.contiguous()
-        feature_f = torch.cat([s_img_proj_f.to(**f32), pred_t_img_embed.to(**f32)], dim=1).repeat_interleave(N, 0)
-        prior_embed = pred_t_img_embed.to(**f32).repeat_interleave(N, 0)
+        if self.use_prior_embed:
+            feature_f = torch.cat([s_img_proj_f.to(**f32), pred_t_img_embed.to(**f32)], dim=1).repeat_interleave(N, 0)
+            prior_embed = pred_t_img_embed.to(**f32).repeat_interleave(N, 0)
+        else:
+            feature_f = s_img_proj_f.to(**f32).repeat_interleave(N, 0)
+            prior_embed = None
         if do_cfg:
             feature_f = torch.cat([torch.zeros_like(feature_f), feature_f], dim=0)
-            prior_embed = torch.cat([torch.zeros_like(prior_embed), prior_embed], dim=0)
-        feature_f, prior_embed = feature_f.contiguous(), prior_embed.contiguous()
+            if prior_embed is not None:
+                prior_embed = torch.cat([torch.zeros_like(prior_embed), prior_embed], dim=0)
+        feature_f = feature_f.contiguous()
+        if prior_embed is not None:
+            prior_embed = prior_embed.contiguous()
 
         # ---- timesteps, latents (ref :472-487)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
@@ -159,14 +169,18 @@ class Stage2_InpaintDiffusionPipeline:
                                 my_pose_cond=pose_cond, return_dict=False)[0]
                 if do_cfg:
                     g = torch.empty_like(lat)
-                    ops.cfg_step(eps.float().contiguous(), True, float(guidance_scale), None, None, None, eps_out=g)
+                    eps = eps.float().contiguous()
+                    ops.cfg_step(eps, True, float(guidance_scale), None, None, None, eps_out=g)
+                    if guidance_rescale > 0.0:   # ref :514-516
+                        g = rescale_noise_cfg(g, eps[eps.shape[0] // 2:], guidance_rescale)
                     eps = g
                 lat = self.scheduler.step(eps, t, lat, **extra, return_dict=False)[0]
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, lat)
         else:
             lat = self._run_fused(lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg,
-                                  float(guidance_scale), eta, use_graph, callback, callback_steps)
+                                  float(guidance_scale), eta, use_graph, callback, callback_steps,
+                                  float(guidance_rescale) if do_cfg else 0.0)
 
         if output_type == "latent" or self.vae is None:
             images = lat
@@ -184,11 +198,17 @@ class Stage2_InpaintDiffusionPipeline:
         x_in = ops.assemble_input(st["lat"], st["rep"], st["mask"], st["masked"], st["x_in"])
         eps = unet._forward_nhwc(x_in, B, h, w, st["timesteps"], st["feature_f"], st["prior_embed"], st["pose"],
                                  step_dev=st["step"])
-        ops.cfg_step(eps, st["rep"] == 2, st["g"], st["lat"], st["lat"], st["coef"], st["step"])
+        if st["gr"] > 0.0:   # CFG -> rescale_noise_cfg (ref :510-516) -> scheduler update
+            n = eps.shape[0] // 2
+            ops.cfg_step(eps, True, st["g"], None, None, None, eps_out=st["eps_g"])
+            ops.rescale_noise_cfg(st["eps_g"], eps[n:], st["eps_g"], st["gr"])
+            ops.cfg_step(st["eps_g"], False, 1.0, st["lat"], st["lat"], st["coef"], st["step"])
+        else:
+            ops.cfg_step(eps, st["rep"] == 2, st["g"], st["lat"], st["lat"], st["coef"], st["step"])
         ops.advance_step(st["step"])
 
     def _run_fused(self, lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, g, eta, use_graph,
-                   callback, callback_steps):
+                   callback, callback_steps, guidance_rescale=0.0):
         unet, dev = self.unet, self.device
         if unet._w is None:
             unet._pack()
@@ -196,13 +216,15 @@ class Stage2_InpaintDiffusionPipeline:
         N, _, h, w = lat.shape
         rep = 2 if do_cfg else 1
         B = rep * N
-        key = (B, h, w, n, rep, tuple(feature_f.shape), tuple(mask.shape), tuple(masked.shape), tuple(pose_cond.shape))
+        key = (B, h, w, n, rep, tuple(feature_f.shape), tuple(mask.shape), tuple(masked.shape), tuple(pose_cond.shape),
+               prior_embed is None)
         st = self._st if self._graph_key == key else {}
         if not st:
             st.update(B=B, h=h, w=w, rep=rep,
                       lat=torch.empty_like(lat), mask=torch.empty_like(mask), masked=torch.empty_like(masked),
                       pose=torch.empty_like(pose_cond), feature_f=torch.empty_like(feature_f),
-                      prior_embed=torch.empty_like(prior_embed),
+                      prior_embed=None if prior_embed is None else torch.empty_like(prior_embed),
+                      eps_g=torch.empty_like(lat),
                       x_in=torch.empty(B, h, w, 64, dtype=ops.BF16, device=dev),
                       step=torch.zeros(1, dtype=torch.int32, device=dev),
                       timesteps=torch.empty(n, dtype=torch.int64, device=dev),
@@ -213,6 +235,8 @@ class Stage2_InpaintDiffusionPipeline:
         changed = False
         for name, src in (("mask", mask), ("masked", masked), ("pose", pose_cond), ("feature_f", feature_f),
                           ("prior_embed", prior_embed)):
+            if src is None:
+                continue
             if not self._graph or not torch.equal(st[name], src):
                 st[name].copy_(src)
                 changed = True
@@ -221,6 +245,9 @@ class Stage2_InpaintDiffusionPipeline:
         st["timesteps"].copy_(timesteps.to(dev))
         st["coef"].copy_(self.scheduler.coefficient_table(eta, device=dev))
         st["g"] = g
+        if st.get("gr", guidance_rescale) != guidance_rescale:
+            self._graph = None
+        st["gr"] = guidance_rescale
         st["step"].zero_()
         self._st, self._graph_key = st, key
         simple_cb = callback is None
@@ -248,3 +275,11 @@ class Stage2_InpaintDiffusionPipeline:
                 if callback is not None and i % callback_steps == 0:
                     callback(i, timesteps[i], st["lat"])
         return st["lat"].clone()
+
+
+class Simple_Stage2_InpaintDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
+    """The reference's variant without the stage-1 prior embedding (stage2_inpaint_pipeline.py:544-887):
+    ``self.unet(x, t, encoder_hidden_states=feature_f, my_pose_cond=pose_cond)`` (:860-862) with a UNet built
+    without ``class_embed_type``; ``pred_t_img_embed`` is ignored."""
+
+    use_prior_embed = False
