@@ -102,3 +102,28 @@ def synth_inputs(cfg: UNetConfig, h: int, w: int, N: int, L_img: int = 257):
     pred = torch.randn(1, 1, cfg.projection_class_embeddings_input_dim or ctx, generator=g(5)) * 0.4
     return dict(latents=latents, masked_latents=ml, st_pose_f=st_pose_f, s_img_proj_f=s_img_proj_f,
                 pred_t_img_embed=pred)
+
+
+def stage3_sample(sd, cfg: UNetConfig, scheduler, *, gen_t_img_latents, s_img_proj_f, latents, num_images_per_prompt: int = 1,
+                  guidance_scale: float = 2.0, num_inference_steps: int = 20) -> torch.Tensor:
+    """Stage-3 refinement loop, /root/reference/src/pipelines/stage3_refined_pipeline.py:483-557, with the batch bug of
+    the reference FIXED (it does not repeat the conditioning for num_images_per_prompt in the
+    CFG branch): conditioning is repeated to N rows; the uncond half has zero context AND zero refine latents (:491-497).
+    UNet input = cat([latents, gen_t_img_latents], 1) (8 channels, :538); stock UNet (no class_labels / pose)."""
+    N = num_images_per_prompt
+    cfg_on = guidance_scale > 1.0
+    feat = s_img_proj_f.repeat(N, 1, 1)
+    gl = gen_t_img_latents.repeat(N, 1, 1, 1)
+    if cfg_on:
+        feat = torch.cat([torch.zeros_like(feat), feat])
+        gl = torch.cat([torch.zeros_like(gl), gl])
+    scheduler.set_timesteps(num_inference_steps)
+    latents = latents * scheduler.init_noise_sigma
+    for t in scheduler.timesteps:
+        x = torch.cat([latents] * 2) if cfg_on else latents
+        eps = unet_forward(sd, cfg, torch.cat([x, gl], 1), t, feat, None, None)
+        if cfg_on:
+            u, c = eps.chunk(2)
+            eps = u + guidance_scale * (c - u)
+        latents = scheduler.step(eps, t, latents)
+    return latents

@@ -289,7 +289,9 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
         emb = emb + timestep_mlp(sd, "class_embedding.", class_labels.squeeze(1))
     tap("emb", emb)
     # 2. pre-process (ref :742) -- the one PCDMs-specific op
-    x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1) + my_pose_cond
+    x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    if my_pose_cond is not None:  # stock UNet2DConditionModel (stage 3) has no pose feature
+        x = x + my_pose_cond
     tap("conv_in", x)
     # 3. down (ref :746-761)
     skips: List[Tensor] = [x]

@@ -283,3 +283,57 @@ class Simple_Stage2_InpaintDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
     without ``class_embed_type``; ``pred_t_img_embed`` is ignored."""
 
     use_prior_embed = False
+
+
+class Stage3_RefinedDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
+    """Stage-3 refinement sampler: mirrors ``Stage3_RefinedDiffusionPipeline.__call__``
+    (/root/reference/src/pipelines/stage3_refined_pipeline.py:441-578).  UNet = ``pcdms_amd.UNet2DConditionModel``
+    with ``in_channels=8``; input ``cat([latents, gen_t_img_latents], 1)`` (:538); CFG uncond half = zero context and
+    zero refine latents (:491-497).  The reference forgets to repeat the conditioning for
+    ``num_images_per_prompt`` under CFG (a shape error for N > 1); here it is repeated.
+    ``gen_t_img_latents`` = vae.encode(vae_gen_t_image).sample() * scaling_factor (:483-484; VAE outside the hot path)."""
+
+    @torch.no_grad()
+    def __call__(self, height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 50,
+                 guidance_scale: float = 7.5, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback=None, callback_steps: int = 1, guidance_rescale: float = 0.0,
+                 vae_gen_t_image: Optional[torch.Tensor] = None, s_img_proj_f: Optional[torch.Tensor] = None,
+                 gen_t_img_latents: Optional[torch.Tensor] = None):
+        device = self.device
+        N = num_images_per_prompt
+        f32 = dict(device=device, dtype=torch.float32)
+        if gen_t_img_latents is None:
+            if self.vae is None:
+                raise ValueError("pass gen_t_img_latents=... (VAE encode is outside the hot path) or construct with vae=")
+            gen_t_img_latents = self.vae.encode(vae_gen_t_image.to(device)).latent_dist.sample(generator=generator)
+            gen_t_img_latents = gen_t_img_latents * self.vae.config.scaling_factor
+        do_cfg = guidance_scale > 1.0
+        feat = s_img_proj_f.to(**f32).repeat_interleave(N, 0)
+        gl = gen_t_img_latents.to(**f32).repeat_interleave(N, 0)
+        if do_cfg:
+            feat = torch.cat([torch.zeros_like(feat), feat])
+            gl = torch.cat([torch.zeros_like(gl), gl])
+        feat, gl = feat.contiguous(), gl.contiguous()
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        lat = self.prepare_latents(s_img_proj_f.shape[0] * N, 4, height, width, torch.float32, device, generator, latents)
+        extra = self.prepare_extra_step_kwargs(generator, eta)
+        for i, t in enumerate(self.scheduler.timesteps):
+            x = torch.cat([lat] * 2) if do_cfg else lat
+            x = self.scheduler.scale_model_input(x, t)
+            eps = self.unet(torch.cat([x, gl], dim=1), t, encoder_hidden_states=feat, return_dict=False)[0]
+            if do_cfg:
+                g = torch.empty_like(lat)
+                eps = eps.float().contiguous()
+                ops.cfg_step(eps, True, float(guidance_scale), None, None, None, eps_out=g)
+                if guidance_rescale > 0.0:
+                    g = rescale_noise_cfg(g, eps[eps.shape[0] // 2:], guidance_rescale)
+                eps = g
+            lat = self.scheduler.step(eps, t, lat, **extra, return_dict=False)[0]
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, lat)
+        images = lat if (output_type == "latent" or self.vae is None) else \
+            (self.vae.decode(lat / self.vae.config.scaling_factor, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
+        if not return_dict:
+            return (images, None)
+        return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)

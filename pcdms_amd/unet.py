@@ -92,6 +92,8 @@ def _as_tuple(v, n):
 class Stage2_InapintUNet2DConditionModel:
     """Drop-in for the reference class of the same (sic) name; inference only."""
 
+    _pose_required = True   # the stage-2 forward adds my_pose_cond unconditionally (ref :742)
+
     def __init__(self, **kwargs):
         cfg = dict(_DEFAULT_CONFIG)
         unknown = [k for k in kwargs if k not in cfg and not k.startswith("_")]
@@ -371,7 +373,7 @@ class Stage2_InapintUNet2DConditionModel:
             raise NotImplementedError("cross_attention_kwargs (LoRA scale etc.) is not part of the stage-2 path")
         if self.config.class_embed_type is not None and class_labels is None:
             raise ValueError("class_labels should be provided when num_class_embeds > 0")
-        if my_pose_cond is None:
+        if my_pose_cond is None and self._pose_required:
             raise ValueError("my_pose_cond is required (ref stage2_inpaint_unet_2d_condition.py:742)")
         if sample.dim() != 4 or sample.shape[1] != self.config.in_channels:
             raise ValueError(f"sample must be [B,{self.config.in_channels},h,w], got {tuple(sample.shape)}")
@@ -424,8 +426,8 @@ class Stage2_InapintUNet2DConditionModel:
         temb = ops.small_linear(emb_act, W["temb_w"], W["temb_b"], self._buf("temb", (B, W["temb_n"]), torch.float32))
 
         # ---- step-invariant conditioning (Appendix C-5), cached on tensor identity
-        pose_nhwc = self._cached("pose", pose)
-        if pose_nhwc is None:
+        pose_nhwc = self._cached("pose", pose) if pose is not None else None
+        if pose is not None and pose_nhwc is None:
             if pose.shape[0] not in (1, B) or tuple(pose.shape[1:]) != (boc[0], h, w):
                 raise ValueError(f"my_pose_cond must be [1|{B},{boc[0]},{h},{w}], got {tuple(pose.shape)}")
             pose_nhwc = self._store("pose", pose, ops.nchw_to_nhwc_bf16(
@@ -489,7 +491,8 @@ class Stage2_InapintUNet2DConditionModel:
         # ---- 2. conv_in + pose (ref :742)
         HW = h * w
         x = ops.gemm(x_in, W["conv_in"], self._buf("skip0", (B * HW, boc[0])), conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w),
-                     residual=pose_nhwc.view(-1, boc[0]), res_mod=pose_nhwc.shape[0] * HW)
+                     residual=None if pose_nhwc is None else pose_nhwc.view(-1, boc[0]),
+                     res_mod=0 if pose_nhwc is None else pose_nhwc.shape[0] * HW)
         # ---- 3. down (ref :746-761)
         skips: List[Tuple[torch.Tensor, int, int]] = [(x, h, w)]
         hh, ww = h, w
@@ -646,3 +649,10 @@ def _param_shapes(m: Stage2_InapintUNet2DConditionModel) -> Iterator[Tuple[str, 
 
 # friendlier alias
 Stage2InpaintUNet = Stage2_InapintUNet2DConditionModel
+
+
+class UNet2DConditionModel(Stage2_InapintUNet2DConditionModel):
+    """The stock diffusers ``UNet2DConditionModel`` topology on the same kernels (no pose feature): the stage-3
+    refinement UNet of the reference (``in_channels=8``, stage3_batchtest_refined_model.py:121-126)."""
+
+    _pose_required = False

@@ -109,3 +109,27 @@ def test_simple_pipeline_and_guidance_rescale(gpu_backend):
     b = _call(pipe, inp, gpu_backend.device, N, steps, h, w, mode="reference", guidance_rescale=0.7)
     assert _rel(a, ref) <= 3e-2 and _rel(b, ref) <= 3e-2, (_rel(a, ref), _rel(b, ref))
     assert torch.allclose(a, b, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_stage3_refine_pipeline(gpu_backend):
+    """§8f N2: stock UNet (in_channels 8, no class embedding / pose) + the stage-3 loop vs the oracle restatement."""
+    from oracle.pipeline import stage3_sample
+    from pcdms_amd import Stage3_RefinedDiffusionPipeline, UNet2DConditionModel
+    cfg = UNetConfig.tiny(in_channels=8, class_embed_type=None, projection_class_embeddings_input_dim=None)
+    sd = synth_state_dict(cfg, seed=4, random_affine=True)
+    m = UNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(gpu_backend.device)
+    N, h, w, L, steps = 2, 16, 16, 9, 5
+    g = torch.Generator().manual_seed(8)
+    feat = torch.randn(1, L, 64, generator=g)
+    gl = torch.randn(1, 4, h, w, generator=g) * 0.9
+    lat = torch.randn(N, 4, h, w, generator=g)
+    ref = stage3_sample(sd, cfg, UniPCOracle(), gen_t_img_latents=gl, s_img_proj_f=feat, latents=lat,
+                        num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps)
+    dev = gpu_backend.device
+    pipe = Stage3_RefinedDiffusionPipeline(m, UniPCMultistepScheduler.from_config(SD21))
+    out = pipe(height=h * 8, width=w * 8, gen_t_img_latents=gl.to(dev), s_img_proj_f=feat.to(dev), latents=lat.to(dev),
+               num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent").latents
+    assert _rel(out, ref) <= 3e-2, _rel(out, ref)
