@@ -42,7 +42,7 @@ int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const flo
  *  out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
  *  A (bf16), one of
  *    linear : A[m, k] = (k < c1 ? a[m*lda + k] : a2[m*lda2 + k - c1])      (Linear, 1x1 conv, skip concat)
- *    conv3x3: m = (b, oy, ox) over [B, Ho, Wo]; k = (ky*3+kx)*cin + c; pad 1; stride 1|2;
+ *    conv3x3: m = (b, oy, ox) over [B, Ho, Wo]; k = (ky*3+kx)*cin + c; pad 1 (or no_pad_lo); stride 1|2;
  *             upsample=1 reads a[b, iy>>1, ix>>1, c] (nearest x2 folded in: Upsample2D, K5)
  *  W: packed bf16 [Npad, K] (K contiguous; rows >= N zero).  K % 64 == 0, Npad % 64 == 0.
  *  epilogue: + bias[n] + rowvec[m / rows_per_batch, n] + residual[(m % res_mod), n]  then
@@ -77,6 +77,9 @@ typedef struct pcdm_gemm_params {
     int32_t split_k;   /* > 1: split K over split_k workgroups per tile (PCDM_EPI_STORE only); partial sums in ws */
     float* ws;         /* fp32 workspace, >= split_k * M * Npad floats */
     int64_t ws_floats;
+    int64_t ldw;       /* row stride of W in elements (0 -> K); lets an activation slice act as the [N,K] operand */
+    int32_t no_pad_lo; /* conv: 1 = zero padding at the bottom/right only (taps start AT the output pixel): the VAE
+                          encoder's Downsample2D(padding=0) + F.pad(0,1,0,1); 0 = symmetric padding 1 */
     int32_t tile;      /* 0 = heuristic; 1..10 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
 } pcdm_gemm_params;
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
@@ -121,6 +124,16 @@ int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x, const floa
  * over n = C*H*W elements (unbiased std); cfg_eps / text_eps / out fp32 [N, n]; out may alias cfg_eps. */
 int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_eps, float* out, int N, int64_t n,
                            float guidance_rescale, pcdm_stream_t s);
+/* p[r, c] = softmax_c(scale * s[r, c]) : fp32 [rows, ld_s] -> bf16 [rows, ld_p], cols <= 8192.  The VAE's single-head
+ * d = 512 attention (AutoencoderKL mid block) = pcdm_gemm (K Q^T, fp32) + this + pcdm_gemm (P V). */
+int pcdm_softmax_rows(const float* s_in, void* p_out, int rows, int cols, int64_t ld_s, int64_t ld_p, float scale,
+                      pcdm_stream_t s);
+/* AutoencoderKL helpers (stage2_inpaint_pipeline.py:443-444, :528-532):
+ * gaussian_sample: out[B,zc,HW] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale from moments fp32 [B,2*zc,HW];
+ * image_to_uint8: VaeImageProcessor.postprocess -- x fp32 [B,cstride,HW] (first 3 channels) -> uint8 [B,HW,3]. */
+int pcdm_gaussian_sample(const float* moments, const float* noise, float* out, int B, int zc, int HW, float scale,
+                         pcdm_stream_t s);
+int pcdm_image_to_uint8(const float* x, void* out, int B, int cstride, int HW, pcdm_stream_t s);
 /* y = sum_i c[i] * x_i  (i < nin <= 6), fp32; UniPC predictor/corrector linear combinations. */
 int pcdm_lincomb(float* y, int nin, const float* const* xs, const float* c, int64_t n, pcdm_stream_t s);
 /* *step_dev += 1 */

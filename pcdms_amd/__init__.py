@@ -11,4 +11,6 @@ from .schedulers import DDIMScheduler, DDPMScheduler, UniPCMultistepScheduler  #
 from .unet import (Stage2_InapintUNet2DConditionModel, Stage2InpaintUNet, UNet2DConditionModel,  # noqa: F401
                    UNet2DConditionOutput)
 
+from .vae import AutoencoderKL  # noqa: F401,E402
+
 __version__ = "0.1.0"

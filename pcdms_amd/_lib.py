@@ -37,7 +37,7 @@ class GemmParams(C.Structure):
         ("epilogue", C.c_int32), ("vt_col0", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out2", C.c_void_p), ("ldo2", C.c_int64),
         ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("tile", C.c_int32),
+        ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32),
     ]
 
 
@@ -59,6 +59,9 @@ _SIGS = {
     "pcdm_cfg_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
     "pcdm_lincomb": ([_P, _I, C.POINTER(_P), C.POINTER(_F), _L, _P], C.c_int),
     "pcdm_rescale_noise_cfg": ([_P, _P, _P, _I, _L, _F, _P], C.c_int),
+    "pcdm_softmax_rows": ([_P, _P, _I, _I, _L, _L, _F, _P], C.c_int),
+    "pcdm_gaussian_sample": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
+    "pcdm_image_to_uint8": ([_P, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_advance_step": ([_P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)

@@ -33,7 +33,9 @@ struct GemmArgs {
     int64_t lda, lda2;
     int c1;
     int B, Hi, Wi, Ho, Wo, stride, upsample, cin;
+    int pad;   // conv: 1 = symmetric zero padding 1 (default); 0 = bottom/right only (VAE encoder Downsample2D)
     const u16* w;
+    int64_t ldw;   // row stride of W in elements (>= K)
     int M, N, K, Npad;
     const float* bias;
     const float* rowvec;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             const int Hv_ = p.Hi << p.upsample, Wv_ = p.Wi << p.upsample;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
-                const int iy = y * p.stride + tp / 3 - 1, ix = x * p.stride + tp % 3 - 1;
+                const int iy = y * p.stride + tp / 3 - p.pad, ix = x * p.stride + tp % 3 - p.pad;
                 if (iy >= 0 && iy < Hv_ && ix >= 0 && ix < Wv_) a_mask[j] |= 1 << tp;
             }
         } else {
@@ -153,11 +155,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int rl = (wave * BI + j) * 8 + srow;
-        b_off[j] = (uint32_t)((int64_t)(n0 + rl) * p.K * 2) + (uint32_t)(spos ^ ((rl >> 1) & 7)) * 16u;
+        b_off[j] = (uint32_t)((int64_t)(n0 + rl) * p.ldw * 2) + (uint32_t)(spos ^ ((rl >> 1) & 7)) * 16u;
     }
     // conv: descriptor base = a - (Wi+1) pixels, so that tap (ky,kx) is the NON-NEGATIVE uniform offset
     // (ky*Wi + kx)*cin*2; the bytes in front of the tensor are never touched (those taps are masked)
-    const BufRsrc rs_a = make_buf_rsrc(CONV ? (const char*)p.a - (int64_t)(p.Wi + 1) * p.cin * 2 : (const char*)p.a);
+    const BufRsrc rs_a = make_buf_rsrc(CONV ? (const char*)p.a - (int64_t)p.pad * (p.Wi + 1) * p.cin * 2 : (const char*)p.a);
     const BufRsrc rs_a2 = make_buf_rsrc(p.a2 ? (const void*)p.a2 : (const void*)p.a);
     const BufRsrc rs_w = make_buf_rsrc(p.w);
 
@@ -535,7 +537,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (p->rows_per_batch <= 0) return -1;
     // 32-bit buffer offsets: every operand must stay below 2 GiB
     const int64_t lim = 0x7fffffffLL;
-    if ((int64_t)p->Npad * p->K * 2 >= lim) return -2;
+    if ((int64_t)p->Npad * (p->ldw > 0 ? p->ldw : p->K) * 2 >= lim) return -2;
     if (p->conv ? ((int64_t)p->B * p->Hi * p->Wi * p->cin * 2 + ((int64_t)p->Wi + 1) * p->cin * 2 >= lim)
                 : ((int64_t)p->M * p->lda * 2 >= lim || (p->a2 && (int64_t)p->M * p->lda2 * 2 >= lim))) return -2;
     GemmArgs a;
@@ -546,7 +548,10 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.c1 = p->a2 ? p->c1 : p->K;
     a.B = p->B; a.Hi = p->Hi; a.Wi = p->Wi; a.Ho = p->Ho; a.Wo = p->Wo;
     a.stride = p->stride; a.upsample = p->upsample; a.cin = p->cin;
+    a.pad = p->no_pad_lo ? 0 : 1;
     a.w = (const u16*)p->w;
+    a.ldw = p->ldw > 0 ? p->ldw : p->K;
+    if (a.ldw < p->K || a.ldw % 8) return -1;
     a.M = p->M; a.N = p->N; a.K = p->K; a.Npad = p->Npad;
     a.bias = p->bias;
     a.rowvec = p->rowvec;
@@ -571,7 +576,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     }
     if (p->conv) {
         if (p->cin % BK || p->K != 9 * p->cin || (p->stride != 1 && p->stride != 2) || p->a2) return -1;
-        if (p->upsample && p->stride != 1) return -1;
+        if (p->upsample && (p->stride != 1 || p->no_pad_lo)) return -1;
         if (p->M != p->B * p->Ho * p->Wo) return -1;
     } else {
         if (p->a2 && (p->c1 % BK || p->c1 <= 0 || p->c1 >= p->K)) return -1;

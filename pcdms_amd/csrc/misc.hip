@@ -191,6 +191,74 @@ __global__ __launch_bounds__(1024) void rescale_cfg_kernel(const float* __restri
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = a[i] * f;
 }
 
+// p[r, :] = softmax(scale * s[r, :]) as bf16; one workgroup (256 threads) per row, the row lives in registers
+// (cols <= 8192), fp32 max / exp / sum with wave64 shuffles + LDS across the 4 waves.  Used by the VAE's single-head
+// d=512 attention (two MFMA GEMMs around it), SURVEY.md §8f N1.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, u16* __restrict__ p, int cols,
+                                                           int64_t ld_s, int64_t ld_p, float scale_log2e) {
+    __shared__ float red[4];
+    const float* sr = s + (int64_t)blockIdx.x * ld_s;
+    u16* pr = p + (int64_t)blockIdx.x * ld_p;
+    const int t = threadIdx.x;
+    float v[32];
+    float mx = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = t + 256 * i;
+        v[i] = c < cols ? sr[c] * scale_log2e : -1e30f;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        v[i] = fast_exp2(v[i] - mx);
+        sum += (t + 256 * i < cols) ? v[i] : 0.f;
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[t >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = t + 256 * i;
+        if (c < cols) pr[c] = f2bf(v[i] * inv);
+    }
+}
+
+// DiagonalGaussianDistribution.sample() * scaling_factor (ref stage2_inpaint_pipeline.py:443-444):
+// moments fp32 [B, 2*zc, HW] (mean | logvar); out = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale
+__global__ void gaussian_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise,
+                                       float* __restrict__ out, int zc, int HW, float scale, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, c, pix)
+    if (i >= total) return;
+    const int64_t chw = (int64_t)zc * HW;
+    const int64_t b = i / chw, r = i - b * chw;
+    const float mean = mom[b * 2 * chw + r];
+    float lv = mom[b * 2 * chw + chw + r];
+    lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+    const float z = noise ? noise[i] : 0.f;
+    out[i] = (mean + __expf(0.5f * lv) * z) * scale;
+}
+
+// VaeImageProcessor.postprocess: (x/2+0.5).clamp(0,1) -> NHWC -> round(255 x) -> uint8.  x fp32 [B, cstride>=3, HW] (NCHW)
+__global__ void image_to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int cstride, int HW,
+                                      int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, pix)
+    if (i >= total) return;
+    const int64_t b = i / HW, pix = i - b * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = x[(b * cstride + c) * HW + pix] * 0.5f + 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i * 3 + c] = (uint8_t)rintf(v * 255.0f);
+    }
+}
+
 __global__ void advance_step_kernel(int32_t* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
 }
@@ -284,6 +352,33 @@ extern "C" int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_ep
                                       float guidance_rescale, pcdm_stream_t s) {
     if (!cfg_eps || !text_eps || !out || N <= 0 || n <= 1) return -1;
     PCDM_LAUNCH(rescale_cfg_kernel, dim3(N), dim3(1024), 0, (hipStream_t)s, cfg_eps, text_eps, out, n, guidance_rescale);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_softmax_rows(const float* s_in, void* p_out, int rows, int cols, int64_t ld_s, int64_t ld_p, float scale,
+                                 pcdm_stream_t s) {
+    if (!s_in || !p_out || rows <= 0 || cols <= 0 || cols > 8192) return -1;
+    PCDM_LAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)s, s_in, (u16*)p_out, cols, ld_s, ld_p,
+                scale * 1.44269504088896341f);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_gaussian_sample(const float* moments, const float* noise, float* out, int B, int zc, int HW, float scale,
+                                    pcdm_stream_t s) {
+    if (!moments || !out || B <= 0 || zc <= 0 || HW <= 0) return -1;
+    const int64_t total = (int64_t)B * zc * HW;
+    PCDM_LAUNCH(gaussian_sample_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, moments, noise, out, zc, HW, scale,
+                total);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_image_to_uint8(const float* x, void* out, int B, int cstride, int HW, pcdm_stream_t s) {
+    if (!x || !out || B <= 0 || cstride < 3 || HW <= 0) return -1;
+    const int64_t total = (int64_t)B * HW;
+    PCDM_LAUNCH(image_to_uint8_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, x, (uint8_t*)out, cstride, HW, total);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -139,16 +139,18 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
-         use_bias: bool = True, split_k: int = 1) -> torch.Tensor:
+         use_bias: bool = True, split_k: int = 1, w_ld: int = 0) -> torch.Tensor:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``."""
     p = GemmParams()
-    _c(a, BF16)
+    assert a.dtype == BF16 and a.stride(-1) == 1 and (conv is None or a.is_contiguous())
     p.a = _ptr(a)
+    p.ldw = w_ld
     if conv is not None:
         p.conv = 1
         p.B, p.Hi, p.Wi, p.Ho, p.Wo = conv["B"], conv["Hi"], conv["Wi"], conv["Ho"], conv["Wo"]
         p.stride, p.upsample, p.cin = conv.get("stride", 1), conv.get("upsample", 0), pw.cin
+        p.no_pad_lo = conv.get("no_pad_lo", 0)
         assert a.numel() == p.B * p.Hi * p.Wi * pw.cin, (a.shape, pw.cin)
         M = p.B * p.Ho * p.Wo
     else:
@@ -156,7 +158,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.lda = a.stride(0)
         p.c1 = a.shape[1]
         if a2 is not None:
-            _c(a2, BF16)
+            assert a2.dtype == BF16 and a2.stride(-1) == 1
             p.a2 = _ptr(a2)
             p.lda2 = a2.stride(0)
             assert a.shape[1] + a2.shape[1] == pw.K
@@ -185,7 +187,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     stream = _stream(a)
     split = 1
     if tile == 0 and AUTOTUNE and a.is_cuda:
-        key = (M, pw.Npad, pw.K, p.conv, p.stride, p.upsample, epilogue, a2 is not None, residual is not None)
+        key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
+               a2 is not None, residual is not None)   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
         if tile == 0 and not torch.cuda.is_current_stream_capturing():
             tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device)
@@ -395,6 +398,15 @@ def rescale_noise_cfg(cfg_eps: torch.Tensor, text_eps: torch.Tensor, out: torch.
     N = cfg_eps.shape[0]
     _chk(_lib.lib().pcdm_rescale_noise_cfg(_ptr(cfg_eps), _ptr(text_eps), _ptr(out), N, cfg_eps.numel() // N,
                                            float(guidance_rescale), _stream(out)), "pcdm_rescale_noise_cfg")
+    return out
+
+
+def softmax_rows(s: torch.Tensor, out: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp32 [rows, cols] -> bf16 [rows, cols] = softmax(scale * s, dim=-1)."""
+    assert s.dtype == torch.float32 and out.dtype == BF16 and s.stride(1) == 1 and out.stride(1) == 1
+    rows, cols = s.shape
+    _chk(_lib.lib().pcdm_softmax_rows(_ptr(s), _ptr(out), rows, cols, s.stride(0), out.stride(0), float(scale), _stream(s)),
+         "pcdm_softmax_rows")
     return out
 
 

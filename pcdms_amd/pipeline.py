@@ -182,14 +182,26 @@ class Stage2_InpaintDiffusionPipeline:
                                   float(guidance_scale), eta, use_graph, callback, callback_steps,
                                   float(guidance_rescale) if do_cfg else 0.0)
 
-        if output_type == "latent" or self.vae is None:
-            images = lat
-        else:
-            img = self.vae.decode(lat / self.vae.config.scaling_factor, return_dict=False)[0]
-            images = (img / 2 + 0.5).clamp(0, 1)
+        images = self._postprocess(lat, output_type)
         if not return_dict:
             return (images, None)
         return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
+
+    def _postprocess(self, lat, output_type):
+        """ref :528-532: vae.decode(latents / scaling_factor) + VaeImageProcessor.postprocess."""
+        if output_type == "latent" or self.vae is None:
+            return lat
+        z = lat / self.vae.config.scaling_factor
+        if output_type == "pt":
+            return (self.vae.decode(z, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
+        u8 = self.vae.decode_to_uint8(z)            # uint8 [N, H, W, 3] on the device (HIP kernel)
+        if output_type == "uint8":
+            return u8
+        arr = u8.cpu().numpy()
+        if output_type == "np":
+            return arr.astype("float32") / 255.0
+        from PIL import Image                        # "pil" (the reference default)
+        return [Image.fromarray(a) for a in arr]
 
     # ------------------------------------------------------------------------------------------
     def _step_eager(self, st):
@@ -332,8 +344,7 @@ class Stage3_RefinedDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
             lat = self.scheduler.step(eps, t, lat, **extra, return_dict=False)[0]
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, lat)
-        images = lat if (output_type == "latent" or self.vae is None) else \
-            (self.vae.decode(lat / self.vae.config.scaling_factor, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
+        images = self._postprocess(lat, output_type)
         if not return_dict:
             return (images, None)
         return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
