@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the separate VAE encode/decode timing (SURVEY.md §8f N1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,6 +141,8 @@ def main():
                    "e2e_tflops_per_gpu": round(value * FLOP_PER_IMAGE * (h * w) / (64 * 88) / world / 1e12, 1)},
     }
 
+    if rank == 0 and not args.no_vae:
+        result["config"].update(vae_timing(dev, N, args.height, 2 * args.width, ms_per_step))
     if rank == 0 and not args.no_roofline:
         result["roofline"] = kernel_roofline(pipe, ops, dinp, N, h, w)
     if rank == 0 and not args.no_cpu_baseline:
@@ -149,6 +152,31 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def vae_timing(dev, N, height, width, ms_per_call):
+    """Outside the headline metric (VAE is a 'next' row): one encode of the masked canvas + decode/uint8 of the N
+    samples with the full SD-2.1 AutoencoderKL topology (83.65 M params, synthetic weights), HIP path."""
+    from oracle.vae import VAEConfig, synth_state_dict as vae_sd
+    from pcdms_amd.vae import AutoencoderKL
+    vae = AutoencoderKL()
+    vae.load_state_dict(vae_sd(VAEConfig(), 0))
+    vae.to(dev)
+    x = torch.rand(1, 3, height, width, device=dev) * 2 - 1
+    z = torch.randn(N, 4, height // 8, width // 8, device=dev)
+
+    def t(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    enc = t(lambda: vae.encode(x).latent_dist.sample())
+    dec = t(lambda: vae.decode_to_uint8(z))
+    return {"vae_encode_ms": round(enc, 2), "vae_decode_uint8_ms": round(dec, 2),
+            "images_per_s_incl_vae": round(N / ((ms_per_call + enc + dec) * 1e-3), 4)}
 
 
 def kernel_roofline(pipe, ops, dinp, N, h, w):

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import math
+import os
 from pathlib import Path
 from dataclasses import dataclass
 from typing import Optional, Sequence, Union
@@ -291,7 +292,8 @@ def save_tuning(path: Path = TUNING_FILE, note: str = "") -> None:
     Path(path).write_text(json.dumps(tab, indent=0))
 
 
-load_tuning()
+if os.environ.get("PCDM_NO_TUNING_TABLE") != "1":   # (the online autotuner alone, for A/B runs)
+    load_tuning()
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,
