@@ -145,7 +145,7 @@ def main():
         result["config"].update(vae_timing(dev, N, args.height, 2 * args.width, ms_per_step))
     if rank == 0 and not args.no_roofline:
         result["roofline"] = kernel_roofline(pipe, ops, dinp, N, h, w)
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(sd, cfg, inp, N, args.ddim_steps)
     if use_dist:
         dist.barrier()

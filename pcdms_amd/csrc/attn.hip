@@ -20,6 +20,8 @@
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 
+#include <type_traits>
+
 namespace {
 constexpr int KB = 64;     // keys per tile
 constexpr int QPW = 32;    // queries per wave
@@ -76,17 +78,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
         }
     };
 
-    f32x16 oacc[2];
+    f32x16 oacc[2], lacc;      // lacc: row sums on the matrix pipe (every register of a lane holds sum_k P[q, k])
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = lacc[r] = 0.f;
+    float m_run = -1e30f;
+    const u16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
 
     const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);  // K row permutation
     const int sw_k = (pi >> 1) & 7, sw_v = (col >> 1) & 7;             // fragment-read swizzles (rows 32-aligned)
     const int nkb = (Lk + KB - 1) / KB;
-    issue_tile(0, 0);
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1, key0 = kb * KB;
+
+    // one KV tile; CUR is a compile-time stage index so every LDS address is base + immediate
+    auto tile_step = [&](int kb, auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
+        const int key0 = kb * KB;
         glds_wait();       // this wave's DMAs of tile kb have landed ...
         __syncthreads();   // ... everybody's have; and everybody is done reading buffer cur^1
         if (kb + 1 < nkb) issue_tile(key0 + KB, cur ^ 1);
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
                 for (int r = 0; r < 16; ++r)
                     if (key0 + 32 * kf + 16 * (r >> 3) + 8 * hh + (r & 7) >= Lk) s[kf][r] = -1e30f;
         }
-        // ---- online softmax (fp32)
+        // ---- online softmax (fp32): max over this lane's 32 keys + the partner lane's 32
         float mx = s[0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
@@ -122,23 +127,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
         const float alpha = fast_exp2((m_run - m_new) * c);
         const float mc = m_new * c;
         m_run = m_new;
-        float lsum = 0.f;
         u16x8 pf[4];
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(fmaf(s[kf][r], c, -mc));
-                lsum += pv;
-                pf[2 * kf + (r >> 3)][r & 7] = f2bf(pv);
-            }
-        l_run = l_run * alpha + lsum;
+            for (int r = 0; r < 16; ++r)
+                pf[2 * kf + (r >> 3)][r & 7] = f2bf(fast_exp2(fmaf(s[kf][r], c, -mc)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             oacc[0][r] *= alpha;
             oacc[1][r] *= alpha;
         }
-        // ---- O^T += V^T P^T
+        lacc[0] *= alpha;   // only register 0 is ever read back: l = l*alpha + sum_k P (added by the MFMA below)
+        // ---- O^T += V^T P^T ; row sums += 1^T P^T (the softmax denominator is accumulated by the matrix pipe,
+        //      which has slack here, instead of 32 VALU adds per tile -- the kernel is VALU-bound at d = 64)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
@@ -146,9 +148,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
                 const u16x8 vfrag = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
                 oacc[df] = mfma_32x32x16(vfrag, pf[s4], oacc[df]);
             }
+            lacc = mfma_32x32x16(ones, pf[s4], lacc);
         }
+    };
+
+    issue_tile(0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        tile_step(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < nkb) tile_step(kb + 1, std::integral_constant<int, 1>{});
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = lacc[0];   // sum over all keys (the MFMA contracts over both lane halves)
     const float inv = 1.0f / l_tot;
     if (qvalid) {
         u16* op = o + ((int64_t)b * Lq + qrow) * ldo + h * 64;
