@@ -52,6 +52,7 @@ int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const flo
  *                       with m = b*rows_per_batch + t, out2 pitch ldo2 (V^T for pcdm_flash_attn)
  *    PCDM_EPI_NCHW_F32: out as fp32 [B, N, rows_per_batch] (conv_out -> eps in NCHW) */
 enum { PCDM_EPI_STORE = 0, PCDM_EPI_GEGLU = 1, PCDM_EPI_SPLIT_VT = 2, PCDM_EPI_NCHW_F32 = 3 };
+enum { PCDM_ACT_NONE = 0, PCDM_ACT_SILU = 1, PCDM_ACT_GELU = 2 };
 typedef struct pcdm_gemm_params {
     const void* a;
     const void* a2;
@@ -80,7 +81,9 @@ typedef struct pcdm_gemm_params {
     int64_t ldw;       /* row stride of W in elements (0 -> K); lets an activation slice act as the [N,K] operand */
     int32_t no_pad_lo; /* conv: 1 = zero padding at the bottom/right only (taps start AT the output pixel): the VAE
                           encoder's Downsample2D(padding=0) + F.pad(0,1,0,1); 0 = symmetric padding 1 */
-    int32_t tile;      /* 0 = heuristic; 1..10 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
+    int32_t tile;      /* 0 = heuristic; 1..12 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
+    int32_t act;       /* PCDM_ACT_*: out = act(acc + bias + rowvec) + residual (not with PCDM_EPI_GEGLU).  SiLU: the convs of
+                          ControlNetConditioningEmbedding (stage2_batchtest_inpaint_model.py:101); GELU(erf): ImageProjModel_p (:54-56) */
 } pcdm_gemm_params;
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 

@@ -12,5 +12,6 @@ from .unet import (Stage2_InapintUNet2DConditionModel, Stage2InpaintUNet, UNet2D
                    UNet2DConditionOutput)
 
 from .vae import AutoencoderKL  # noqa: F401,E402
+from .cond import ControlNetConditioningEmbedding, ImageProjModel_p  # noqa: F401,E402
 
 __version__ = "0.1.0"

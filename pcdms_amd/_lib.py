@@ -37,7 +37,7 @@ class GemmParams(C.Structure):
         ("epilogue", C.c_int32), ("vt_col0", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out2", C.c_void_p), ("ldo2", C.c_int64),
         ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32),
+        ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32), ("act", C.c_int32),
     ]
 
 

@@ -53,11 +53,16 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int split_k;   // > 1: K range split over split_k workgroups per tile, fp32 partials to ws, reduced by splitk_reduce_kernel
     float* ws;
+    int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
     int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs
 };
 
 // 16 zero bytes: the LDS-DMA source of every padded / out-of-range chunk (halo, rows >= M)
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vm_then_barrier() {
@@ -375,6 +380,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[e + 4] += t1[e]; }
                     }
+                    if (p.act) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+                    }
                     if (p.residual) {
                         const u16x8 rv = *(const u16x8*)(p.residual + (int64_t)(m % p.res_mod) * p.ldr + n);
 #pragma unroll
@@ -438,6 +447,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += tv[e];
                 }
+                if (p.act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
                 if (p.residual) {
                     const u16x4 rv = *(const u16x4*)(p.residual + rrow + n);
 #pragma unroll
@@ -474,6 +487,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     for (int s = 0; s < p.split_k; ++s) v += *(const f32x4*)(p.ws + ((int64_t)s * p.M + m) * p.Npad + n);
     if (p.bias) v += *(const f32x4*)(p.bias + n);
     if (p.rowvec) v += *(const f32x4*)(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n);
+    if (p.act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    }
     if (p.residual) {
         const u16x4 rv = *(const u16x4*)(p.residual + (int64_t)(m % p.res_mod) * p.ldr + n);
 #pragma unroll
@@ -568,6 +585,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.ldo2 = p->ldo2;
     a.tiles_m = a.tiles_n = 0;
     a.debug = p->tile >> 8;
+    a.act = p->act;
+    if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act && p->epilogue == PCDM_EPI_GEGLU)) return -1;
     a.split_k = p->split_k > 1 ? p->split_k : 1;
     a.ws = p->ws;
     if (a.split_k > 1) {

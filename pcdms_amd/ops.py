@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import GemmParams
 
 EPI_STORE, EPI_GEGLU, EPI_SPLIT_VT, EPI_NCHW_F32 = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 BF16 = torch.bfloat16
 LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
 AUTOTUNE = True                    # pick the GEMM tile configuration per problem shape at first use (GPU only)
@@ -140,7 +141,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
-         use_bias: bool = True, split_k: int = 1, w_ld: int = 0) -> torch.Tensor:
+         use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE) -> torch.Tensor:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``."""
     p = GemmParams()
@@ -179,6 +180,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.ldr = residual.stride(0) if residual.dim() == 2 else pw.N
         p.res_mod = res_mod
     p.epilogue = epilogue
+    p.act = act
     p.vt_col0 = vt_col0
     p.out = _ptr(out)
     p.ldo = out.stride(0) if (out.dim() == 2 and epilogue != EPI_NCHW_F32) else pw.N
