@@ -123,6 +123,13 @@ int pcdm_f32_to_bf16(const float* x, void* y, int64_t n, pcdm_stream_t s);
  * Optionally writes the guided eps (eps_out) and x0 = c0x*x + c0e*eps is left to the host scheduler. */
 int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x, const float* noise, float* x_prev,
                   float* eps_out, const float* coef, const int32_t* step_dev, int64_t n, pcdm_stream_t s);
+/* Stage-1 prior: CFG combine (src/pipelines/stage1_prior_pipeline.py:467-471) + diffusers
+ * UnCLIPScheduler.step (:478-483) + optional affine read-out (post_process_latents, stage1_prior_transformer.py:299-301).
+ * pred [2N or N, n/N] fp32 (uncond rows first); HOST coefficients c8 = {p_x, p_e, clip, c_x0, c_x, c_noise, out_scale,
+ * out_shift}:  x0 = clamp(p_x*x + p_e*pred_guided, +-clip) (clip <= 0: none);
+ * x_prev = (c_x0*x0 + c_x*x + c_noise*noise) * out_scale + out_shift.  x_prev may alias x. */
+int pcdm_unclip_step(const float* pred, int cfg, float g, const float* x, const float* noise, float* x_prev,
+                     const float* c8, int64_t n, pcdm_stream_t s);
 /* rescale_noise_cfg (stage2_inpaint_pipeline.py:52-63): out = gr * cfg * std(text)/std(cfg) + (1-gr) * cfg, per sample
  * over n = C*H*W elements (unbiased std); cfg_eps / text_eps / out fp32 [N, n]; out may alias cfg_eps. */
 int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_eps, float* out, int N, int64_t n,

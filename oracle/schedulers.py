@@ -235,3 +235,75 @@ class UniPCOracle:
             self.lower_order_nums += 1
         self.step_index += 1
         return prev
+
+
+def _betas_for_alpha_bar(T: int, max_beta: float = 0.999) -> torch.Tensor:
+    """diffusers ``betas_for_alpha_bar`` (cosine / "squaredcos_cap_v2")."""
+    def alpha_bar(t):
+        return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    return torch.tensor([min(1 - alpha_bar((i + 1) / T) / alpha_bar(i / T), max_beta) for i in range(T)], dtype=torch.float32)
+
+
+class UnCLIPOracle:
+    """diffusers 0.24.0 ``UnCLIPScheduler`` as the stage-1 prior uses it (called at
+    /root/reference/src/pipelines/stage1_prior_pipeline.py:439-440 ``set_timesteps`` and :478-483
+    ``step(pred, timestep=t, sample=latents, prev_timestep=...)``).  Defaults = the Kandinsky-2.2 prior's
+    ``scheduler_config.json`` (prediction_type "sample", clip +-10, "fixed_small_log" variance, cosine betas).
+    PARITY UNPINNED ([D-0.24] block, restated from the published algorithm)."""
+
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, variance_type="fixed_small_log", clip_sample=True,
+                 clip_sample_range=10.0, prediction_type="sample", beta_schedule="squaredcos_cap_v2"):
+        assert beta_schedule == "squaredcos_cap_v2" and variance_type == "fixed_small_log"
+        assert prediction_type in ("sample", "epsilon")
+        self.T = num_train_timesteps
+        self.betas = _betas_for_alpha_bar(self.T)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.clip_sample, self.clip_sample_range, self.prediction_type = clip_sample, clip_sample_range, prediction_type
+        self.timesteps = torch.arange(self.T - 1, -1, -1)
+
+    def set_timesteps(self, n: int, device=None):
+        ratio = (self.T - 1) / (n - 1)
+        self.timesteps = torch.from_numpy((np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64))
+
+    def scale_model_input(self, x, t=None):
+        return x
+
+    def coefficients(self, t: int, prev_t: Optional[int]):
+        """pred_prev = c_x0 * clip(x0) + c_x * x + std * noise (std = 0 at t = 0)."""
+        if prev_t is None:
+            prev_t = t - 1
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        if prev_t == t - 1:
+            beta, alpha = float(self.betas[t]), float(self.alphas[t])
+        else:
+            beta = 1 - a_t / a_prev
+            alpha = 1 - beta
+        c_x0 = math.sqrt(a_prev) * beta / b_t
+        c_x = math.sqrt(alpha) * b_prev / b_t
+        std = 0.0
+        if t > 0:
+            var = max(b_prev / b_t * beta, 1e-20)
+            std = math.exp(0.5 * math.log(var))
+        return c_x0, c_x, std, a_t
+
+    def step(self, model_output, t, sample, prev_timestep=None, generator=None, variance_noise=None):
+        t = int(t)
+        prev_t = None if prev_timestep is None else int(prev_timestep)
+        c_x0, c_x, std, a_t = self.coefficients(t, prev_t)
+        if self.prediction_type == "epsilon":
+            x0 = (sample - math.sqrt(1 - a_t) * model_output) / math.sqrt(a_t)
+        else:
+            x0 = model_output
+        if self.clip_sample:
+            x0 = x0.clamp(-self.clip_sample_range, self.clip_sample_range)
+        prev = c_x0 * x0 + c_x * sample
+        if t > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+            prev = prev + std * variance_noise
+        return prev

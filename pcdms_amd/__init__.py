@@ -7,11 +7,12 @@ Drop-in objects for the reference's ``pipe.unet`` / ``pipe.scheduler``
 from .parallel import run_sharded, split_list_into_chunks  # noqa: F401
 from .pipeline import (Simple_Stage2_InpaintDiffusionPipeline, Stage2_InpaintDiffusionPipeline,  # noqa: F401
                        Stage2_InpaintDiffusionPipelineOutput, Stage3_RefinedDiffusionPipeline)
-from .schedulers import DDIMScheduler, DDPMScheduler, UniPCMultistepScheduler  # noqa: F401
+from .schedulers import DDIMScheduler, DDPMScheduler, UnCLIPScheduler, UniPCMultistepScheduler  # noqa: F401
 from .unet import (Stage2_InapintUNet2DConditionModel, Stage2InpaintUNet, UNet2DConditionModel,  # noqa: F401
                    UNet2DConditionOutput)
 
 from .vae import AutoencoderKL  # noqa: F401,E402
 from .cond import ControlNetConditioningEmbedding, ImageProjModel_p  # noqa: F401,E402
+from .prior import Stage1_PriorPipeline, Stage1_PriorTransformer  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -142,6 +142,23 @@ __global__ void cfg_step_kernel(const float* __restrict__ eps, int cfg, float g,
     }
 }
 
+// UnCLIPScheduler.step on a [N, n/N] vector (stage-1 prior): guided prediction -> x0 -> clip -> posterior mean (+ noise),
+// then an optional affine read-out (post_process_latents).  c = {p_x, p_e, clip, c_x0, c_x, c_noise, out_scale, out_shift}.
+struct UnclipArgs { float c[8]; };
+__global__ void unclip_step_kernel(const float* __restrict__ pred, int cfg, float g, const float* __restrict__ x,
+                                   const float* __restrict__ noise, float* __restrict__ x_prev, UnclipArgs a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float e = pred[i];
+    if (cfg) e = e + g * (pred[n + i] - e);
+    const float xi = x[i];
+    float x0 = a.c[0] * xi + a.c[1] * e;
+    if (a.c[2] > 0.f) x0 = fminf(fmaxf(x0, -a.c[2]), a.c[2]);
+    float v = a.c[3] * x0 + a.c[4] * xi;
+    if (noise) v += a.c[5] * noise[i];
+    x_prev[i] = v * a.c[6] + a.c[7];
+}
+
 struct LinArgs {
     const float* x[6];
     float c[6];
@@ -332,6 +349,16 @@ extern "C" int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x,
     if (!eps || n <= 0 || (x_prev && (!x || !coef))) return -1;
     PCDM_LAUNCH(cfg_step_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, eps, cfg, g, x, noise, x_prev, eps_out,
                 coef, step_dev, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_unclip_step(const float* pred, int cfg, float g, const float* x, const float* noise, float* x_prev,
+                                const float* c8, int64_t n, pcdm_stream_t s) {
+    if (!pred || !x || !x_prev || !c8 || n <= 0) return -1;
+    UnclipArgs a;
+    for (int i = 0; i < 8; ++i) a.c[i] = c8[i];
+    PCDM_LAUNCH(unclip_step_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, pred, cfg, g, x, noise, x_prev, a, n);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -384,6 +384,20 @@ def cfg_step(eps: torch.Tensor, cfg: bool, g: float, x: Optional[torch.Tensor], 
                                   _ptr(coef), _ptr(step_dev), n, _stream(eps)), "pcdm_cfg_step")
 
 
+def unclip_step(pred: torch.Tensor, cfg: bool, g: float, x: torch.Tensor, noise: Optional[torch.Tensor], out: torch.Tensor,
+                coefs: Sequence[float]) -> torch.Tensor:
+    """pcdm_unclip_step: coefs = (p_x, p_e, clip, c_x0, c_x, c_noise, out_scale, out_shift); fp32 tensors."""
+    _c(pred, torch.float32); _c(x, torch.float32); _c(out, torch.float32)
+    n = x.numel()
+    assert pred.numel() == (2 * n if cfg else n) and out.numel() == n and len(coefs) == 8
+    if noise is not None:
+        assert _c(noise, torch.float32).numel() == n
+    carr = (C.c_float * 8)(*[float(c) for c in coefs])
+    _chk(_lib.lib().pcdm_unclip_step(_ptr(pred), int(cfg), float(g), _ptr(x), _ptr(noise), _ptr(out), carr, n, _stream(x)),
+         "pcdm_unclip_step")
+    return out
+
+
 def lincomb(out: torch.Tensor, xs: Sequence[torch.Tensor], cs: Sequence[float]) -> torch.Tensor:
     n = len(xs)
     assert 1 <= n <= 6 and len(cs) == n

@@ -52,6 +52,10 @@ def _betas(cfg) -> np.ndarray:
         return torch.linspace(cfg.beta_start, cfg.beta_end, T, dtype=torch.float32).numpy()
     if cfg.beta_schedule == "scaled_linear":
         return (torch.linspace(cfg.beta_start ** 0.5, cfg.beta_end ** 0.5, T, dtype=torch.float32) ** 2).numpy()
+    if cfg.beta_schedule == "squaredcos_cap_v2":   # diffusers betas_for_alpha_bar (cosine), max_beta 0.999
+        def alpha_bar(t):
+            return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        return np.asarray([min(1 - alpha_bar((i + 1) / T) / alpha_bar(i / T), 0.999) for i in range(T)], dtype=np.float32)
     raise NotImplementedError(f"{cfg.beta_schedule} does is not implemented")
 
 
@@ -351,4 +355,67 @@ class UniPCMultistepScheduler(_Base):
         if self.lower_order_nums < c.solver_order:
             self.lower_order_nums += 1
         self._step_index += 1
+        return (prev,) if not return_dict else SchedulerOutput(prev)
+
+
+class UnCLIPScheduler(_Base):
+    """Stand-in for diffusers 0.24.0 ``UnCLIPScheduler`` at the stage-1 prior's call sites
+    (/root/reference/src/pipelines/stage1_prior_pipeline.py:439-440 ``set_timesteps`` / ``timesteps``, :279
+    ``init_noise_sigma``, :478-483 ``step(pred, timestep=t, sample=latents, prev_timestep=...)``).
+    Class defaults are diffusers'; the Kandinsky-2.2 prior's ``scheduler_config.json`` (prediction_type "sample",
+    clip_sample_range 10, "fixed_small_log") arrives through ``from_config`` / ``from_pretrained``.
+    Scalar coefficient math on the host (float64), the tensor update is one HIP kernel (``pcdm_unclip_step``)."""
+
+    _defaults = dict(num_train_timesteps=1000, variance_type="fixed_small_log", clip_sample=True, clip_sample_range=1.0,
+                     prediction_type="epsilon", beta_schedule="squaredcos_cap_v2", trained_betas=None)
+    KANDINSKY22_PRIOR = dict(num_train_timesteps=1000, variance_type="fixed_small_log", clip_sample=True,
+                             clip_sample_range=10.0, prediction_type="sample", beta_schedule="squaredcos_cap_v2")
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c.variance_type != "fixed_small_log" or c.prediction_type not in ("epsilon", "sample"):
+            raise NotImplementedError("UnCLIP variant outside the stage-1 path (learned_range variance / v-prediction)")
+        self._betas64 = self.betas.numpy().astype(np.float64)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = (self.config.num_train_timesteps - 1) / (num_inference_steps - 1)
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    def step_coefficients(self, t: int, prev_t: Optional[int] = None):
+        """(p_x, p_e, clip, c_x0, c_x, c_noise): x0 = clamp(p_x x + p_e pred, +-clip); prev = c_x0 x0 + c_x x + c_noise z."""
+        c = self.config
+        if prev_t is None:
+            prev_t = t - 1
+        a_t = float(self._ac[t])
+        a_prev = float(self._ac[prev_t]) if prev_t >= 0 else 1.0
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        if prev_t == t - 1:
+            beta = float(self._betas64[t])
+            alpha = 1 - beta
+        else:
+            beta = 1 - a_t / a_prev
+            alpha = 1 - beta
+        if c.prediction_type == "epsilon":
+            p_x, p_e = 1 / math.sqrt(a_t), -math.sqrt(1 - a_t) / math.sqrt(a_t)
+        else:
+            p_x, p_e = 0.0, 1.0
+        clip = float(c.clip_sample_range) if c.clip_sample else 0.0
+        std = math.exp(0.5 * math.log(max(b_prev / b_t * beta, 1e-20))) if t > 0 else 0.0
+        return p_x, p_e, clip, math.sqrt(a_prev) * beta / b_t, math.sqrt(alpha) * b_prev / b_t, std
+
+    def step(self, model_output, timestep, sample, prev_timestep=None, generator=None, variance_noise=None,
+             return_dict: bool = True):
+        t = int(timestep)
+        co = self.step_coefficients(t, None if prev_timestep is None else int(prev_timestep))
+        e, x = _f32(model_output), _f32(sample)
+        noise = None
+        if co[5] > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(e.shape, generator=generator, dtype=torch.float32,
+                                             device=generator.device if generator is not None else e.device)
+            noise = _f32(variance_noise.to(e.device))
+        prev = ops.unclip_step(e, False, 0.0, x, noise, torch.empty_like(x), (*co, 1.0, 0.0)).to(sample.dtype)
         return (prev,) if not return_dict else SchedulerOutput(prev)

@@ -23,8 +23,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from oracle import prior as OP
 from oracle import unet as O
-from oracle.schedulers import DDIMOracle, UniPCOracle
+from oracle.schedulers import DDIMOracle, UnCLIPOracle, UniPCOracle
 
 
 def _sd(mod: nn.Module):
@@ -291,6 +292,57 @@ def get_up_block(up_block_type, **kw):
     return {"UpBlock2D": UpBlock2D, "CrossAttnUpBlock2D": CrossAttnUpBlock2D}[up_block_type](**kw)
 
 
+# ------------------------------------------------------------------ stage-1 prior blocks
+class _AttnBias(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+
+
+class _GELU(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.proj = nn.Linear(c, 4 * c)
+
+
+class BasicTransformerBlock(nn.Module):
+    """Self-attention-only block as stage1_prior_transformer.py:108-119 constructs it (parameter names = diffusers')."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, activation_fn="geglu", attention_bias=False, **kw):
+        super().__init__()
+        assert activation_fn == "gelu" and attention_bias and dim == num_attention_heads * attention_head_dim
+        self.h = num_attention_heads
+        self.norm1, self.attn1 = nn.LayerNorm(dim), _AttnBias(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = nn.Module()
+        self.ff.net = nn.ModuleList([_GELU(dim), nn.Dropout(0.0), nn.Linear(4 * dim, dim)])
+
+    def forward(self, hidden_states, attention_mask=None, **kw):
+        assert attention_mask is None
+        return OP.transformer_block(_sd(self), "", hidden_states.float(), self.h)
+
+
+class UnCLIPSchedulerStub:
+    """diffusers-style wrapper over UnCLIPOracle; variance noise comes from ``noises`` (one per step), because the
+    reference draws it from the global RNG (stage1_prior_pipeline.py:478)."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, noises):
+        self.impl, self.noises, self.i = UnCLIPOracle(), noises, 0
+
+    def set_timesteps(self, n, device=None):
+        self.impl.set_timesteps(n)
+        self.timesteps = self.impl.timesteps
+        self.i = 0
+
+    def step(self, model_output, timestep, sample, prev_timestep=None, generator=None, return_dict=True):
+        out = self.impl.step(model_output.float(), timestep, sample.float(), prev_timestep=prev_timestep,
+                             variance_noise=self.noises[self.i])
+        self.i += 1
+        return types.SimpleNamespace(prev_sample=out)
+
+
 # ------------------------------------------------------------------ pipeline-side stubs
 class DiffusionPipeline:
     def register_modules(self, **kw):
@@ -315,6 +367,9 @@ class DiffusionPipeline:
 
             def update(s, *a):
                 pass
+
+            def __iter__(s):
+                return iter(iterable)
         return _PB()
 
 
@@ -405,13 +460,18 @@ def install():
     mod("diffusers.loaders", UNet2DConditionLoadersMixin=type("UNet2DConditionLoadersMixin", (), {}),
         LoraLoaderMixin=type("LoraLoaderMixin", (), {}))
     u = mod("diffusers.utils", BaseOutput=BaseOutput, logging=logging, deprecate=lambda *a, **k: None,
-            is_accelerate_available=lambda: False, is_accelerate_version=lambda *a: False)
+            is_accelerate_available=lambda: False, is_accelerate_version=lambda *a: False,
+            replace_example_docstring=lambda doc: (lambda fn: fn))
     u.__path__ = []
     mod("diffusers.utils.torch_utils", randn_tensor=randn_tensor)
     m = mod("diffusers.models", AutoencoderKL=FakeVAE)
     m.__path__ = []
     mod("diffusers.models.activations", get_activation=lambda name: nn.SiLU())
     mod("diffusers.models.attention_processor", AttentionProcessor=_Any, AttnProcessor=_Any)
+    mod("diffusers.models.attention", BasicTransformerBlock=BasicTransformerBlock)
+    pl = mod("diffusers.pipelines")
+    pl.__path__ = []
+    mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
     mod("diffusers.models.embeddings", GaussianFourierProjection=_Any, TextImageProjection=_Any,
         TextImageTimeEmbedding=_Any, TextTimeEmbedding=_Any, TimestepEmbedding=TimestepEmbedding, Timesteps=Timesteps)
     mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
@@ -420,4 +480,4 @@ def install():
         UNetMidBlock2DSimpleCrossAttn=_Any, UpBlock2D=UpBlock2D, get_down_block=get_down_block, get_up_block=get_up_block)
     mod("diffusers.image_processor", VaeImageProcessor=VaeImageProcessor)
     mod("diffusers.schedulers", KarrasDiffusionSchedulers=_Any, DDIMScheduler=_Any, DPMSolverMultistepScheduler=_Any,
-        EulerAncestralDiscreteScheduler=_Any, EulerDiscreteScheduler=_Any, LMSDiscreteScheduler=_Any, PNDMScheduler=_Any)
+        EulerAncestralDiscreteScheduler=_Any, EulerDiscreteScheduler=_Any, LMSDiscreteScheduler=_Any, PNDMScheduler=_Any, UnCLIPScheduler=_Any)

@@ -1,0 +1,157 @@
+"""Stage-1 prior: pcdms_amd.prior (HIP) vs oracle/prior.py (fp32 CPU) and the golden fixture produced by
+the reference's own ``Stage1_PriorTransformer.forward`` / ``Stage1_PriorPipeline.__call__`` (tests/golden/ref_wiring_prior.npz).
+
+Stated tolerance: bf16 tokens through L residual blocks vs fp32: rel-L2 <= 3e-2 on the predicted embedding and on the
+sampled image embedding; the oracle itself must match the fixture to fp32 round-off (1e-5).
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prior as O
+from oracle.schedulers import UnCLIPOracle
+from pcdms_amd import Stage1_PriorPipeline, Stage1_PriorTransformer, UnCLIPScheduler
+
+GOLD = Path(__file__).resolve().parent / "golden" / "ref_wiring_prior.npz"
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _kwargs(cfg):
+    return dict(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, num_layers=cfg.num_layers,
+                embedding_dim=cfg.embedding_dim, num_embeddings=cfg.num_embeddings, additional_embeddings=cfg.additional_embeddings)
+
+
+def _fixture():
+    z = np.load(GOLD)
+    cfg = O.PriorConfig(num_attention_heads=int(z["num_attention_heads"]), num_layers=int(z["num_layers"]))
+    sd = O.synth_state_dict(cfg, int(z["seed"]))
+    from tests.golden.make_reference_wiring_fixtures import weights_checksum
+    assert math.isclose(weights_checksum(sd), float(z["weights_checksum"]), rel_tol=1e-9), "synthetic weights drifted"
+    return z, cfg, sd
+
+
+def test_param_contract():
+    cfg = O.PriorConfig()
+    m = Stage1_PriorTransformer(**_kwargs(cfg))
+    exp = m.expected_shapes()
+    assert exp == {k: tuple(v) for k, v in O.param_shapes(cfg)}
+    assert sum(math.prod(s) for s in exp.values()) == O.param_count(cfg) == 1_027_166_208
+    with pytest.raises(NotImplementedError):
+        Stage1_PriorTransformer(embedding_dim=768)
+    with pytest.raises(RuntimeError):
+        Stage1_PriorTransformer(**_kwargs(O.PriorConfig.tiny())).load_state_dict({"proj_in.weight": torch.zeros(128, 1024)})
+
+
+def test_oracle_matches_reference_fixture():
+    """oracle.prior == the reference's own forward / pipeline wiring (fp32, CPU)."""
+    z, cfg, sd = _fixture()
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    pred = O.prior_forward(sd, cfg, t("x"), int(z["timestep"]), t("proj_embedding"), t("s_pose_b"), t("t_pose_b"))
+    assert torch.allclose(pred, t("pred"), atol=1e-5, rtol=1e-5)
+    out = O.stage1_sample(sd, cfg, UnCLIPOracle(), s_embed=t("s_embed"), s_pose=t("s_pose"), t_pose=t("t_pose"), latents=t("latents"),
+                          noises=list(t("noises")), num_inference_steps=int(z["steps"]), guidance_scale=0)
+    assert torch.allclose(out, t("image_embeds"), atol=1e-5, rtol=1e-5)
+
+
+def test_unclip_scheduler_known_answers(backend):
+    dev = backend.device
+    s, o = UnCLIPScheduler(**UnCLIPScheduler.KANDINSKY22_PRIOR), UnCLIPOracle()
+    s.set_timesteps(20); o.set_timesteps(20)
+    assert s.timesteps.tolist() == o.timesteps.tolist() and s.timesteps[0] == 999 and s.timesteps[-1] == 0
+    assert s.timesteps.tolist()[:4] == [999, 946, 894, 841] and s.init_noise_sigma == 1.0
+    # cosine schedule known answers (closed form): alpha_bar(0 -> 1/1000), clipped last beta
+    assert abs(float(s.alphas_cumprod[0]) - math.cos(0.009 / 1.008 * math.pi / 2) ** 2 / math.cos(0.008 / 1.008 * math.pi / 2) ** 2) < 1e-6
+    assert abs(float(s.betas[-1]) - 0.999) < 1e-7
+    g = torch.Generator().manual_seed(0)
+    x, e, z = (torch.randn(3, 64, generator=g) * 4 for _ in range(3))
+    ts = s.timesteps.tolist()
+    for i in (0, 7, 18, 19):
+        prev = None if i == 19 else ts[i + 1]
+        ref = o.step(e, ts[i], x, prev_timestep=prev, variance_noise=z)
+        got = s.step(e.to(dev), ts[i], x.to(dev), prev_timestep=prev, variance_noise=z.to(dev)).prev_sample
+        backend.sync()
+        assert torch.allclose(got.cpu(), ref, atol=2e-5, rtol=2e-5), i
+    se, oe = UnCLIPScheduler(prediction_type="epsilon", clip_sample_range=2.0), UnCLIPOracle(prediction_type="epsilon", clip_sample_range=2.0)
+    got = se.step(e.to(dev), 500, x.to(dev), variance_noise=z.to(dev), return_dict=False)[0]
+    backend.sync()
+    assert torch.allclose(got.cpu(), oe.step(e, 500, x, variance_noise=z), atol=2e-5, rtol=2e-5)
+    with pytest.raises(NotImplementedError):
+        UnCLIPScheduler(variance_type="learned_range")
+
+
+def _build(backend, cfg, sd):
+    m = Stage1_PriorTransformer(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    return m.to(backend.device)
+
+
+def test_prior_forward_vs_fixture_and_oracle(backend):
+    z, cfg, sd = _fixture()
+    m = _build(backend, cfg, sd)
+    dev = backend.device
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    pred = m(t("x").to(dev), torch.tensor(int(z["timestep"])), t("proj_embedding").to(dev), t("s_pose_b").to(dev),
+             t("t_pose_b").to(dev)).predicted_image_embedding
+    backend.sync()
+    assert pred.shape == (2, 1024) and pred.dtype == torch.float32
+    assert _rel(pred, t("pred")) <= 3e-2, _rel(pred, t("pred"))
+    # second call, new x_t / timestep, same conditioning tensors (static tokens cached), tuple return
+    g = torch.Generator().manual_seed(5)
+    x2 = torch.randn(2, 1, 1024, generator=g)
+    pe, sp, tp = t("proj_embedding").to(dev), t("s_pose_b").to(dev), t("t_pose_b").to(dev)
+    m(x2.to(dev), 10, pe, sp, tp)
+    p2 = m(x2.to(dev), 631, pe, sp, tp, return_dict=False)[0]
+    backend.sync()
+    ref2 = O.prior_forward(sd, cfg, x2, 631, t("proj_embedding"), t("s_pose_b"), t("t_pose_b"))
+    assert _rel(p2, ref2) <= 3e-2, _rel(p2, ref2)
+    with pytest.raises(NotImplementedError):
+        m(x2.to(dev), 1, pe, sp, tp, attention_mask=torch.ones(2, 2))
+
+
+def test_prior_pipeline(backend):
+    """reference-driver settings (guidance 0, N=1) against the fixture; CFG + N=2 against the oracle loop."""
+    z, cfg, sd = _fixture()
+    m = _build(backend, cfg, sd)
+    dev = backend.device
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    pipe = Stage1_PriorPipeline(m).to(dev)
+    pipe.enable_xformers_memory_efficient_attention()
+    out = pipe(s_embed=t("s_embed").to(dev), s_pose=t("s_pose").to(dev), t_pose=t("t_pose").to(dev), num_images_per_prompt=1,
+               num_inference_steps=int(z["steps"]), latents=t("latents").to(dev), guidance_scale=0, variance_noises=list(t("noises")))
+    backend.sync()
+    assert out.negative_image_embeds is None and out[0].shape == (1, 1024)
+    assert _rel(out.image_embeds, t("image_embeds")) <= 3e-2, _rel(out.image_embeds, t("image_embeds"))
+    if backend.is_emu:
+        return
+    g = torch.Generator().manual_seed(8)
+    lat = torch.randn(2, 1024, generator=g)
+    noises = [torch.randn(2, 1024, generator=g) for _ in range(5)]
+    ref = O.stage1_sample(sd, cfg, UnCLIPOracle(), s_embed=t("s_embed"), s_pose=t("s_pose"), t_pose=t("t_pose"), latents=lat,
+                          noises=noises, num_inference_steps=5, guidance_scale=2.5, num_images_per_prompt=2)
+    got = pipe(s_embed=t("s_embed"), s_pose=t("s_pose"), t_pose=t("t_pose"), num_images_per_prompt=2, num_inference_steps=5,
+               latents=lat, guidance_scale=2.5, variance_noises=noises, return_dict=False)[0]
+    assert _rel(got, ref) <= 3e-2, _rel(got, ref)
+
+
+@pytest.mark.gpu
+def test_prior_full_size(gpu_backend):
+    """The 1.03 B-parameter configuration of the driver (32 heads x 64, 20 blocks): one forward, B = 2, vs the oracle."""
+    cfg = O.PriorConfig()
+    sd = O.synth_state_dict(cfg, 2)
+    m = _build(gpu_backend, cfg, sd)
+    g = torch.Generator().manual_seed(3)
+    x, emb = torch.randn(2, 1, 1024, generator=g), torch.randn(2, 1, 1024, generator=g) * 0.4
+    sp, tp = torch.rand(2, 1, 36, generator=g), torch.rand(2, 1, 36, generator=g)
+    dev = gpu_backend.device
+    pred = m(x.to(dev), 789, emb.to(dev), sp.to(dev), tp.to(dev))[0]
+    ref = O.prior_forward(sd, cfg, x, 789, emb, sp, tp)
+    assert _rel(pred, ref) <= 3e-2, _rel(pred, ref)
