@@ -173,7 +173,9 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
     }
 }
 
-// One wave per row; up to 3 octets per lane (C <= 1536); exact two-pass variance in registers.
+// One wave per row; up to NO octets per lane (NO = 3: C <= 1536, the UNet's widths; NO = 8: C <= 4096, the stage-1 prior's
+// 2048); exact two-pass variance in registers.
+template <int NO>
 __global__ __launch_bounds__(kThreads) void layernorm_kernel(const u16* __restrict__ x, u16* __restrict__ y,
                                                            int rows, int C, float eps,
                                                            const float* __restrict__ gamma,
@@ -183,10 +185,10 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const u16* __restri
     const bool valid = row < rows;  // keep whole waves alive for the shuffles
     const int noct = C / 8;
     const int64_t base = (int64_t)(valid ? row : 0) * C;
-    float v[3][8];
+    float v[NO][8];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NO; ++j) {
         const int oc = lane + 64 * j;
         if (oc < noct) {
             const u16x8 u = *(const u16x8*)(x + base + oc * 8);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const u16* __restri
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NO; ++j) {
         const int oc = lane + 64 * j;
         if (oc < noct) {
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const u16* __restri
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
     if (!valid) return;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NO; ++j) {
         const int oc = lane + 64 * j;
         if (oc < noct) {
             const f32x4 g0 = *(const f32x4*)(gamma + oc * 8), g1 = *(const f32x4*)(gamma + oc * 8 + 4);
@@ -266,10 +268,15 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
 
 extern "C" int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma,
                               const float* beta, pcdm_stream_t s) {
-    if (!x || !y || rows <= 0 || C % 8 || C > 1536 || C <= 0) return -1;
+    if (!x || !y || rows <= 0 || C % 8 || C > 4096 || C <= 0) return -1;
     const int rpb = kThreads / 64;
-    PCDM_LAUNCH(layernorm_kernel, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, (hipStream_t)s, (const u16*)x,
-                (u16*)y, rows, C, eps, gamma, beta);
+    if (C <= 1536) {
+        PCDM_LAUNCH(layernorm_kernel<3>, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, (hipStream_t)s, (const u16*)x,
+                    (u16*)y, rows, C, eps, gamma, beta);
+    } else {
+        PCDM_LAUNCH(layernorm_kernel<8>, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, (hipStream_t)s, (const u16*)x,
+                    (u16*)y, rows, C, eps, gamma, beta);
+    }
     PCDM_CHECK_LAUNCH();
     return 0;
 }
