@@ -543,6 +543,12 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         case 10: return launch_gemm<128, 64, 2, 2, 3, CONV>(a, st);   // 4 waves,  72 KiB, 2 blocks / CU
         case 11: return launch_gemm<256, 128, 4, 2, 3, CONV, true>(a, st);  // as 1, staggered wave groups
         case 12: return launch_gemm<256, 64, 4, 2, 3, CONV, true>(a, st);   // as 6, staggered wave groups
+        // N-narrow tiles whose waves still own 64x64 (4 fragment loads per 4 MFMAs instead of 3 per 2: the 64x32 wave
+        // tiles of 3/5/6 run at ~75 % of the LDS read bandwidth) and whose epilogue writes whole 128-byte lines
+        case 13: return launch_gemm<256, 64, 4, 1, 2, CONV>(a, st);   // 4 waves,  80 KiB, 2 blocks / CU
+        case 14: return launch_gemm<256, 64, 4, 1, 3, CONV>(a, st);   // 4 waves, 120 KiB, 1 block / CU
+        case 15: return launch_gemm<128, 64, 2, 1, 2, CONV>(a, st);   // 2 waves,  48 KiB, 3 blocks / CU
+        case 16: return launch_gemm<512, 64, 8, 1, 2, CONV>(a, st);   // 8 waves, 144 KiB, 1 block / CU
         default: return -1;
     }
 }
@@ -606,7 +612,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     int tile = p->tile & 0xff;
     const bool n128 = p->Npad % 128 == 0;
     const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11;
-    if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128) return -1;  // GEGLU pairs need a 64-wide wave tile
+    if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile
     if (tile == 0) {
         const int64_t t256 = (int64_t)((p->M + 255) / 256) * (p->Npad / 128);
         const int64_t t128 = (int64_t)((p->M + 127) / 128) * (p->Npad / 128);

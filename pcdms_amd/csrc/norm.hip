@@ -10,9 +10,12 @@
 // on the input side.
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
+#include <cstdlib>
 
 namespace {
 constexpr int kGnMaxChunks = 64;
+constexpr int kGnUnroll = 4;   // independent 16-byte loads in flight per thread (the passes are HBM-latency bound); measured:
+                               // 128 chunks x 8 loads was 25 % slower at 64x88 (per-block reduction tail dominates)
 constexpr int kGnMaxC = 4096;
 constexpr int kThreads = 256;
 
@@ -52,17 +55,16 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         if (active && oc < g.noct) {
-            // 4 independent 16-byte loads in flight per thread (the loop is HBM-latency bound otherwise)
-            for (int r = r0 + rp; r < r1; r += 4 * g.rows_par) {
-                u16x8 v[4];
+            for (int r = r0 + rp; r < r1; r += kGnUnroll * g.rows_par) {
+                u16x8 v[kGnUnroll];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kGnUnroll; ++u) {
                     const int rr = r + u * g.rows_par;
                     const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     v[u] = rr < r1 ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + rr, oc * 8) : z;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kGnUnroll; ++u)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float f = bf2f(v[u][e]);
@@ -119,21 +121,39 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
     const int rp = t / g.tpr, oc0 = t - rp * g.tpr;
     const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
     const int gs = C / groups;
-    // finish the statistics (every block of batch row b redoes this tiny reduction: groups x nchunk x 2 floats,
-    // fp64, fixed order -> bit-identical in every block and run to run; saves a launch per GroupNorm)
-    for (int grp = t; grp < groups; grp += kThreads) {
+    // finish the statistics (every block of batch row b redoes this tiny reduction: groups x nchunk x 2 floats, fixed
+    // order -> bit-identical in every block and run to run; saves a launch per GroupNorm).  All 256 threads take part:
+    // thread (sub, grp) sums chunks sub, sub+NSUB, ... with its loads in flight together (a serial 64-deep chain of
+    // dependent L2 round trips per group cost more than the streaming pass on the small instances), then the NSUB
+    // partials are combined in fp64.
+    __shared__ double psum[kThreads * 2];
+    {
+        const int nsub = kThreads / groups > 0 ? kThreads / groups : 1;   // groups <= 256
+        const int sub = t / groups, grp = t - sub * groups;
         double s = 0.0, q = 0.0;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const float* ps = part + (((int64_t)b * nchunk + ch) * groups + grp) * 2;
-            s += (double)ps[0];
-            q += (double)ps[1];
+        if (sub < nsub) {
+            for (int ch = sub; ch < nchunk; ch += nsub) {
+                const float* ps = part + (((int64_t)b * nchunk + ch) * groups + grp) * 2;
+                s += (double)ps[0];
+                q += (double)ps[1];
+            }
         }
-        const double cnt = (double)HW * gs;
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stat[2 * grp] = (float)mean;
-        stat[2 * grp + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        psum[2 * t] = s;
+        psum[2 * t + 1] = q;
+        __syncthreads();
+        if (t < groups) {
+            s = q = 0.0;
+            for (int j = 0; j < nsub; ++j) {
+                s += psum[2 * (j * groups + t)];
+                q += psum[2 * (j * groups + t) + 1];
+            }
+            const double cnt = (double)HW * gs;
+            const double mean = s / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stat[2 * t] = (float)mean;
+            stat[2 * t + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     if (rp >= g.rows_par) return;
@@ -149,15 +169,15 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
             sc[e] = rstd * gamma[c];
             sh[e] = beta[c] - mean * sc[e];
         }
-        for (int r = r0 + rp; r < r1; r += 4 * g.rows_par) {
-            u16x8 v[4];
+        for (int r = r0 + rp; r < r1; r += kGnUnroll * g.rows_par) {
+            u16x8 v[kGnUnroll];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kGnUnroll; ++u) {
                 const int rr = r + u * g.rows_par;
                 if (rr < r1) v[u] = gn_load(x1, C1, x2, C2, (int64_t)b * HW + rr, oc * 8);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kGnUnroll; ++u) {
                 const int rr = r + u * g.rows_par;
                 if (rr >= r1) break;
                 u16x8 o;
@@ -171,6 +191,138 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
             }
         }
     }
+}
+
+// ---- single-pass GroupNorm for instances whose per-(batch, group set) slab fits in registers (UNet levels 1-3: HW <= 1408).
+// One workgroup owns `gpb` consecutive groups (gpb * gs channels = noct octets, the smallest octet-aligned run) of one
+// batch image for ALL rows: the slab is read once into registers (MAXR 16-byte loads in flight per thread), mean and
+// the exact centred variance are reduced in a fixed tree (deterministic), and the normalised rows are written back --
+// one launch and 2 bytes moved per element instead of two launches and 3.  blockIdx -> (batch = id % B, group set = id / B)
+// so that the workgroups sharing 128-byte lines of one image run on the same XCD / L2.
+template <int THREADS>
+__device__ __forceinline__ void gn_block_sum4(float (&x)[4], float* red /* [THREADS/64][4] */) {
+    constexpr int NWV = THREADS / 64;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = wave_sum(x[k]);
+    __syncthreads();   // previous use of `red` is over
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wv * 4 + k] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a = 0.f;
+        for (int w = 0; w < NWV; ++w) a += red[w * 4 + k];
+        x[k] = a;
+    }
+}
+
+// Keeps the slab PACKED (bf16, 4 VGPRs per 8 values) between the three passes: without it the compiler hoists the
+// bf16 -> fp32 conversions out of the passes and holds the whole slab as floats (2x the registers, occupancy 1).
+#ifdef PCDM_EMU
+#define GN_KEEP_PACKED(v) ((void)0)
+#else
+#define GN_KEEP_PACKED(v) asm volatile("" : "+v"(v))
+#endif
+
+template <int THREADS, int MAXR>
+__global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict__ x1, int C1, const u16* __restrict__ x2,
+                                                          int C2, int B, int HW, int gs, int gpb, int noct, float eps,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int fuse_silu, u16* __restrict__ y) {
+    __shared__ float red[(THREADS / 64) * 4];
+    const int C = C1 + C2;
+    const int b = blockIdx.x % B, gset = blockIdx.x / B;
+    const int t = threadIdx.x;
+    const int rows_par = THREADS / noct;
+    const int rp = t / noct, oc = t - rp * noct;
+    const bool active = rp < rows_par;
+    const int cl = oc * 8;                       // first channel of this thread's octet, local to the group set
+    const int c = gset * gpb * gs + cl;          // global channel
+    int ge[8];                                   // local group of each of the 8 channels (an octet spans <= 2 groups)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ge[e] = (cl + e) / gs;
+    u16x8 v[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = rp + i * rows_par;
+        const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[i] = (active && r < HW) ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, c) : z;
+    }
+    // ---- mean
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += bf2f(v[i][e]);   // rows beyond HW hold zeros
+    float sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg[k] += (ge[e] == k) ? s[e] : 0.f;
+    gn_block_sum4<THREADS>(sg, red);
+    const float inv_cnt = 1.0f / ((float)HW * (float)gs);
+    float mean_e[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mean_e[e] = sg[ge[e] & 3] * inv_cnt;
+    // ---- centred variance
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
+    float q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = rp + i * rows_par;
+        if (active && r < HW) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = bf2f(v[i][e]) - mean_e[e];
+                q[e] += d * d;
+            }
+        }
+    }
+    float qg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qg[k] += (ge[e] == k) ? q[e] : 0.f;
+    gn_block_sum4<THREADS>(qg, red);
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float rstd = 1.0f / sqrtf(qg[ge[e] & 3] * inv_cnt + eps);
+        sc[e] = rstd * gamma[c + e];
+        sh[e] = beta[c + e] - mean_e[e] * sc[e];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = rp + i * rows_par;
+        if (r < HW) {
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(v[i][e]) * sc[e] + sh[e];
+                if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
+                o[e] = f2bf(f);
+            }
+            *(u16x8*)(y + ((int64_t)b * HW + r) * C + c) = o;
+        }
+    }
+}
+
+template <int THREADS, int MAXR>
+void launch_gn_fused(hipStream_t st, const u16* x1, int C1, const u16* x2, int C2, int B, int HW, int groups, int gs, int gpb,
+                     int noct, float eps, const float* gamma, const float* beta, int silu, u16* y) {
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_fused_kernel<THREADS, MAXR>), dim3((groups / gpb) * B), dim3(THREADS), 0, st, x1, C1, x2, C2, B,
+                HW, gs, gpb, noct, eps, gamma, beta, silu, y);
 }
 
 // One wave per row; up to NO octets per lane (NO = 3: C <= 1536, the UNet's widths; NO = 8: C <= 4096, the stage-1 prior's
@@ -235,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const u16* __restri
 }
 
 inline int gn_chunks(int HW, int rows_par) {
-    int n = (HW + rows_par * 8 - 1) / (rows_par * 8);
+    int n = (HW + rows_par * kGnUnroll - 1) / (rows_par * kGnUnroll);
     if (n > kGnMaxChunks) n = kGnMaxChunks;
     if (n < 1) n = 1;
     return n;
@@ -254,6 +406,33 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
     if (!x1 || !y || !ws || B <= 0 || HW <= 0 || groups <= 0 || groups > 256) return -1;
     if (C1 % 8 || C2 % 8 || C % groups || C > kGnMaxC || (C2 > 0 && !x2)) return -1;
     hipStream_t st = (hipStream_t)s;
+    {   // single-pass path: the (batch, group set) slab in registers
+        const int gs = C / groups;
+        int gpb = 1;
+        while (gpb <= 4 && (gpb * gs) % 8) ++gpb;
+        const int noct = gpb * gs / 8;
+        // slab per workgroup = HW * noct * 16 bytes; beyond ~352 KiB (level 0: 5632 rows) too few, too long workgroups
+        static const int64_t max_slab = [] {
+            const char* e = getenv("PCDM_GN_FUSED_MAX_KB");   // tuning knob (tools/bench_ops.py); 0 disables the fused path
+            return (int64_t)(e ? atoi(e) : 352) * 1024;
+        }();
+        if (gpb <= 4 && groups % gpb == 0 && noct <= 64 && (int64_t)HW * noct * 16 <= max_slab) {
+            // rows per thread at 256 / 512 / 1024 threads, at most 8 (all loads of the slab in flight at once, <= 128 KiB)
+            auto need = [&](int th) { return (HW + th / noct - 1) / (th / noct); };
+            const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
+            bool done = true;
+#define GN_FUSED(TH, MR) launch_gn_fused<TH, MR>(st, a1, C1, a2, C2, B, HW, groups, gs, gpb, noct, eps, gamma, beta, fuse_silu, (u16*)y)
+            if (need(256) <= 8) GN_FUSED(256, 8);
+            else if (need(512) <= 8) GN_FUSED(512, 8);
+            else if (need(1024) <= 8) GN_FUSED(1024, 8);
+#undef GN_FUSED
+            else done = false;
+            if (done) {
+                PCDM_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+    }
     const GnGeom g = gn_geom(C);
     const int nchunk = gn_chunks(HW, g.rows_par);
     const int rpc = (HW + nchunk - 1) / nchunk;

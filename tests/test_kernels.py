@@ -36,10 +36,18 @@ def close(out, ref, tol=1e-2):
 
 
 # ------------------------------------------------------------------------------------------------ norms
-@pytest.mark.parametrize("case", ["single", "concat_straddle", "wide"])
+@pytest.mark.parametrize("case", ["single", "concat_straddle", "wide", "fused16", "fused32", "fused1k", "two_pass_big"])
 def test_groupnorm(backend, case):
     dev = backend.device
-    if case == "single":
+    if case == "fused16":      # single-pass kernel, 512 threads; group size 10 (octets span two groups)
+        B, HW, C1, C2, G = (2, 700, 80, 0, 8) if backend.is_emu else (8, 32 * 44, 640, 640, 32)
+    elif case == "fused32":
+        B, HW, C1, C2, G = (1, 1500, 40, 40, 8) if backend.is_emu else (8, 32 * 44, 640, 0, 32)
+    elif case == "fused1k":    # group size 60 over a two-source concat (emu: 1024-thread single pass; GPU shape: two-pass)
+        B, HW, C1, C2, G = (1, 500, 160, 80, 4) if backend.is_emu else (8, 32 * 44, 1280, 640, 32)
+    elif case == "two_pass_big":   # slab too large for registers -> stats + apply kernels
+        B, HW, C1, C2, G = (1, 3000, 16, 0, 2) if backend.is_emu else (16, 64 * 88, 320, 0, 32)
+    elif case == "single":
         B, HW, C1, C2, G = (2, 37, 64, 0, 32) if backend.is_emu else (8, 64 * 88, 320, 0, 32)
     elif case == "concat_straddle":  # group size 30: groups straddle the x1|x2 boundary (up-block 640+320)
         B, HW, C1, C2, G = (2, 19, 64, 32, 32) if backend.is_emu else (8, 32 * 44, 640, 320, 32)
@@ -82,9 +90,10 @@ def _gemm_sizes(backend):
     if backend.is_emu:
         return [(70, 128, 64, 2), (200, 64, 192, 3), (130, 128, 128, 1), (300, 192, 128, 4), (97, 320, 64, 5),
                 (150, 192, 64, 6), (140, 256, 128, 7), (90, 320, 64, 8), (260, 192, 128, 9), (100, 256, 64, 10),
-                (300, 320, 128, 11), (270, 64, 128, 11), (130, 128, 64, 12), (257, 448, 64, 12)]
+                (300, 320, 128, 11), (270, 64, 128, 11), (130, 128, 64, 12), (257, 448, 64, 12),
+                (300, 192, 64, 13), (280, 256, 128, 14), (150, 128, 64, 15), (600, 128, 64, 16)]
     return [(45056, 320, 320, 0), (2816, 1280, 1280, 0), (704, 1280, 1280, 0), (11264, 640, 1920, 0),
-            (1000, 192, 320, 0), (999, 64, 128, 1), (999, 128, 128, 4)] + [(777, 2560, 640, t) for t in range(1, 13)]
+            (1000, 192, 320, 0), (999, 64, 128, 1), (999, 128, 128, 4)] + [(777, 2560, 640, t) for t in range(1, 17)]
 
 
 def test_gemm_linear_bias_residual_rowvec(backend):
@@ -179,6 +188,35 @@ def test_gemm_split_vt_and_nchw(backend):
     backend.sync()
     ref4 = (a.float() @ w4.float().t() + b4).view(B, L, 4).permute(0, 2, 1)
     close(o4, ref4, tol=2e-3)
+
+
+def test_gemm_narrow_tiles_geglu_and_conv(backend):
+    """tiles 13-16 (BN = 64, one wave column, 64x64 wave tiles): GEGLU pairs inside one wave, conv gather, M tails."""
+    dev = backend.device
+    M, K, D = (70, 64, 96) if backend.is_emu else (11264, 640, 2560)
+    a = rnd(M, K, seed=30)
+    w = rnd(2 * D, K, seed=31, scale=1 / math.sqrt(K))
+    bias = torch.randn(2 * D, generator=torch.Generator().manual_seed(32)) * 0.5
+    pw = ops.pack_geglu(w.float(), bias, dev)
+    pr = a.float() @ w.float().t() + bias
+    h, g = pr.chunk(2, -1)
+    for tile in (13, 16) if backend.is_emu else (13, 14, 15, 16):
+        out = torch.empty(M, D, dtype=BF16, device=dev)
+        ops.gemm(a.to(dev), pw, out, epilogue=ops.EPI_GEGLU, tile=tile)
+        backend.sync()
+        close(out, h * F.gelu(g))
+    B, H, W, Cin, Cout = (2, 6, 5, 64, 64) if backend.is_emu else (8, 32, 44, 640, 320)
+    x = rnd(B, Cin, H, W, seed=50)
+    wc = rnd(Cout, Cin, 3, 3, seed=51, scale=1 / math.sqrt(9 * Cin))
+    bc = torch.randn(Cout, generator=torch.Generator().manual_seed(52))
+    ref = F.conv2d(x.float(), wc.float(), bc, padding=1).permute(0, 2, 3, 1)
+    pwc = ops.pack_conv3x3(wc.float(), bc, dev)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    for tile in (13, 14, 15, 16):
+        out = torch.empty(B * H * W, Cout, dtype=BF16, device=dev)
+        ops.gemm(xh, pwc, out, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tile=tile)
+        backend.sync()
+        close(out.view(B, H, W, Cout), ref)
 
 
 @pytest.mark.parametrize("mode", ["s1", "s2", "up"])
