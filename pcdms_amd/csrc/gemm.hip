@@ -549,6 +549,8 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         case 14: return launch_gemm<256, 64, 4, 1, 3, CONV>(a, st);   // 4 waves, 120 KiB, 1 block / CU
         case 15: return launch_gemm<128, 64, 2, 1, 2, CONV>(a, st);   // 2 waves,  48 KiB, 3 blocks / CU
         case 16: return launch_gemm<512, 64, 8, 1, 2, CONV>(a, st);   // 8 waves, 144 KiB, 1 block / CU
+        // 256x256: 8 waves x (128x64): 32 MFMAs per wave per K-tile for the same 8 LDS-DMA instructions (1:4 instead of 1:2.7)
+        case 17: return launch_gemm<256, 256, 2, 4, 2, CONV>(a, st);  // 8 waves, 128 KiB, 1 block / CU; N % 256 == 0
         default: return -1;
     }
 }
@@ -620,7 +622,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         else if (n128 && (t128 >= 160 || p->epilogue == PCDM_EPI_GEGLU)) tile = 4;
         else if (!n128 && (int64_t)((p->M + 127) / 128) * (p->Npad / 64) >= 256) tile = 5;
         else tile = 2;
-    } else if (needs128 && !n128) {
+    } else if ((needs128 && !n128) || (tile == 17 && p->Npad % 256)) {
         return -1;
     }
     return p->conv ? dispatch_tile<true>(tile, a, st) : dispatch_tile<false>(tile, a, st);
