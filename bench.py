@@ -186,22 +186,40 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
     st = pipe._st
     st["step"].zero_()
     st["lat"].copy_(dinp["latents"])
+    t_host = 0.0
     for _ in range(2):   # warm
+        t0 = time.perf_counter()
         pipe._step_eager(st)
-    torch.cuda.synchronize()
-    ops.LAUNCH_LOG = []
-    pipe._step_eager(st)
-    torch.cuda.synchronize()
-    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        t_host = time.perf_counter() - t0   # host time to ENQUEUE one eager step (no sync inside)
+        torch.cuda.synchronize()
+    # The events bracket each launch on its stream, so a host that enqueues slower than the GPU executes would add idle
+    # time between an event and its kernel.  Keep the GPU busy with a spin kernel while the whole step (launches +
+    # events) is enqueued behind it, and take the per-launch minimum over 3 repetitions of the (deterministic) step.
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record(); e1.synchronize()
+    cyc_per_s = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+    reps = []
+    for _ in range(3):
+        torch.cuda._sleep(int(cyc_per_s * min(3.0 * t_host + 0.01, 1.0)))
+        ops.LAUNCH_LOG = []
+        pipe._step_eager(st)
+        torch.cuda.synchronize()
+        reps.append(ops.LAUNCH_LOG)
+        ops.LAUNCH_LOG = None
+    assert len({len(r) for r in reps}) == 1
+    log = []
+    for entries in zip(*reps):
+        name, flops, _, _, info = entries[0]
+        log.append((name, flops, min(a.elapsed_time(b) for _, _, a, b, _ in entries), info))
     fam = {}
     tiles = {}
-    for name, flops, e0, e1, info in log:
+    for name, flops, ms, info in log:
         if name == "gemm_kernel":
             tiles[info[-2]] = tiles.get(info[-2], 0) + 1
         f = fam.setdefault(name, [0, 0.0, 0.0])
         f[0] += 1
         f[1] += flops
-        f[2] += e0.elapsed_time(e1) * 1e-3
+        f[2] += ms * 1e-3
     gk = fam["gemm_kernel"]
     achieved = gk[1] / gk[2] / 1e12
     traffic = None
@@ -214,7 +232,7 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
            "launches_per_denoise_step": gk[0], "avg_launch_us": round(gk[2] / gk[0] * 1e6, 2),
            "alg_gflop_per_launch": round(gk[1] / gk[0] / 1e9, 2),
            "tile_configs_used": {str(k): v for k, v in sorted(tiles.items())},
-           "note": "HIP events around each launch of one eager denoise step (UNet batch %d, latent %dx%d)" % (2 * N, h, w)}
+           "note": "HIP events around each launch of one eager denoise step enqueued behind a spin kernel, per-launch min of 3 (UNet batch %d, latent %dx%d)" % (2 * N, h, w)}
     if "flash_attn_kernel" in fam:
         fa = fam["flash_attn_kernel"]
         out["flash_attn_kernel"] = {"achieved": round(fa[1] / fa[2] / 1e12, 1), "launches": fa[0],
