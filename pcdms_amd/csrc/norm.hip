@@ -200,11 +200,12 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
 // one launch and 2 bytes moved per element instead of two launches and 3.  blockIdx -> (batch = id % B, group set = id / B)
 // so that the workgroups sharing 128-byte lines of one image run on the same XCD / L2.
 template <int THREADS>
-__device__ __forceinline__ void gn_block_sum4(float (&x)[4], float* red /* [THREADS/64][4] */) {
+__device__ __forceinline__ void gn_block_sum4(float (&x)[4], int n /* live entries (block-uniform) */, float* red /* [THREADS/64][4] */) {
     constexpr int NWV = THREADS / 64;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = wave_sum(x[k]);
+    for (int k = 0; k < 4; ++k)
+        if (k < n) x[k] = wave_sum(x[k]);
     __syncthreads();   // previous use of `red` is over
     if (lane == 0) {
 #pragma unroll
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int k = 0; k < 4; ++k) sg[k] += (ge[e] == k) ? s[e] : 0.f;
-    gn_block_sum4<THREADS>(sg, red);
+    gn_block_sum4<THREADS>(sg, gpb, red);
     const float inv_cnt = 1.0f / ((float)HW * (float)gs);
     float mean_e[8];
 #pragma unroll
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int k = 0; k < 4; ++k) qg[k] += (ge[e] == k) ? q[e] : 0.f;
-    gn_block_sum4<THREADS>(qg, red);
+    gn_block_sum4<THREADS>(qg, gpb, red);
     if (!active) return;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
