@@ -260,6 +260,9 @@ class Stage2_InpaintDiffusionPipeline:
         if st.get("gr", guidance_rescale) != guidance_rescale:
             self._graph = None
         st["gr"] = guidance_rescale
+        if st.get("w_gen") != getattr(unet, "_pack_gen", 0):   # weights were re-packed (load_state_dict / .to): re-capture
+            self._graph = None
+        st["w_gen"] = getattr(unet, "_pack_gen", 0)
         st["step"].zero_()
         self._st, self._graph_key = st, key
         simple_cb = callback is None

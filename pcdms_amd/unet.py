@@ -270,6 +270,7 @@ class Stage2_InapintUNet2DConditionModel:
         if self._device.type != "cuda" and not _emu():
             raise RuntimeError("Stage2_InapintUNet2DConditionModel runs on the MI355X only: call .to('cuda') "
                                "(there is no CPU implementation)")
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1   # a captured hipGraph holds pointers into the packed weights
         sd, dev = self._sd, self._device
         w: Dict[str, Any] = {}
 

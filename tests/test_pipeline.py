@@ -133,3 +133,41 @@ def test_stage3_refine_pipeline(gpu_backend):
     out = pipe(height=h * 8, width=w * 8, gen_t_img_latents=gl.to(dev), s_img_proj_f=feat.to(dev), latents=lat.to(dev),
                num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent").latents
     assert _rel(out, ref) <= 3e-2, _rel(out, ref)
+
+
+@pytest.mark.gpu
+def test_full_size_properties_config2(gpu_backend):
+    """BASELINE.json configs[1] at FULL size (868.9 M-parameter UNet, latent 64x88, N = 4 => UNet batch 8, 50 DDIM
+    steps, hipGraph), checked through size-independent properties -- the fp32 oracle needs ~40 s per step here:
+
+    * zero ``conv_out``  =>  eps = 0  =>  the 50-step DDIM trajectory is the closed-form rescale of the initial latents
+      (SURVEY.md §8c c): pins the fused CFG + scheduler kernel, the device coefficient table and the graph replay;
+    * run-to-run determinism: the same call twice is bit-identical (fixed-order reductions, no atomics);
+    * sample independence: permuting the N initial latents permutes the outputs (bit-exact: every kernel treats batch
+      rows independently)."""
+    dev = gpu_backend.device
+    cfg = UNetConfig()
+    sd = synth_state_dict(cfg, seed=0)
+    N, h, w, steps = 4, 64, 88, 50
+    inp = synth_inputs(cfg, h, w, N)
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(dev)
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    a = _call(pipe, inp, dev, N, 3, h, w)
+    b = _call(pipe, inp, dev, N, 3, h, w)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    perm = [2, 0, 3, 1]
+    c = _call(pipe, dict(inp, latents=inp["latents"][perm]), dev, N, 3, h, w)
+    assert torch.equal(c, a[perm])
+    sd0 = dict(sd)
+    sd0["conv_out.weight"] = torch.zeros_like(sd["conv_out.weight"])
+    sd0["conv_out.bias"] = torch.zeros_like(sd["conv_out.bias"])
+    m.load_state_dict(sd0)
+    out = _call(pipe, inp, dev, N, steps, h, w)
+    o = DDIMOracle()
+    o.set_timesteps(steps)
+    x = inp["latents"].clone()
+    for t in o.timesteps:
+        x = o.step(torch.zeros_like(x), t, x)
+    assert torch.allclose(out.cpu(), x, atol=1e-5, rtol=1e-5)
