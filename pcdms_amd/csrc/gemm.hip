@@ -64,6 +64,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;
 }
 
+// gated-linear-unit epilogue: GEGLU (diffusers FeedForward, act == 0) or SwiGLU (DINOv2 SwiGLUFFN, act == PCDM_ACT_SILU)
+__device__ __forceinline__ float gate_act(float g, int act) { return act == PCDM_ACT_SILU ? silu_f(g) : gelu_erf_f(g); }
+
 template <int N>
 __device__ __forceinline__ void wait_vm_then_barrier() {
     // counted wait (N LDS-DMA instructions of younger tiles may stay in flight) + raw s_barrier in ONE asm
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = (acc[0][j][4 * rg + e] + bh[e]) * gelu_erf_f(acc[FN - 1][j][4 * rg + e] + bg[e]);
+                        v[e] = (acc[0][j][4 * rg + e] + bh[e]) * gate_act(acc[FN - 1][j][4 * rg + e] + bg[e], p.act);
                     *(f32x4*)(ep + (lane & 31) * EPW + nl) = v;
                 }
             } else {
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[e + 4] += t1[e]; }
                     }
-                    if (p.act) {
+                    if (p.act && !geglu) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
                     }
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                     for (int e = 0; e < 4; ++e) {
                         const float hval = acc[0][j][4 * rg + e] + bh[e];
                         const float gval = acc[FN - 1][j][4 * rg + e] + bg[e];
-                        o[e] = f2bf(hval * gelu_erf_f(gval));
+                        o[e] = f2bf(hval * gate_act(gval, p.act));
                     }
                     *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + no) = o;
                 }
@@ -594,7 +597,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.tiles_m = a.tiles_n = 0;
     a.debug = p->tile >> 8;
     a.act = p->act;
-    if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act && p->epilogue == PCDM_EPI_GEGLU)) return -1;
+    if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act == PCDM_ACT_GELU && p->epilogue == PCDM_EPI_GEGLU)) return -1;
     a.split_k = p->split_k > 1 ? p->split_k : 1;
     a.ws = p->ws;
     if (a.split_k > 1) {
