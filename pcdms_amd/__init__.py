@@ -14,6 +14,6 @@ from .unet import (Stage2_InapintUNet2DConditionModel, Stage2InpaintUNet, UNet2D
 from .vae import AutoencoderKL  # noqa: F401,E402
 from .cond import ControlNetConditioningEmbedding, ImageProjModel_p  # noqa: F401,E402
 from .prior import Stage1_PriorPipeline, Stage1_PriorTransformer  # noqa: F401,E402
-from .encoders import Dinov2Model  # noqa: F401,E402
+from .encoders import CLIPVisionModelWithProjection, Dinov2Model  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -89,3 +89,56 @@ def test_dinov2_giant_shapes(gpu_backend):
     with torch.no_grad():
         ref = hf(x).last_hidden_state
     assert out.shape == (1, 257, 1536) and _rel(out, ref) <= 3e-2, _rel(out, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------- CLIP vision tower
+def _hf_clip(cfg_kw, seed=0):
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as HFClip
+    torch.manual_seed(seed)
+    cfg = CLIPVisionConfig(**cfg_kw)
+    m = HFClip(cfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith(".bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            elif p.dim() == 2 and "position" not in k:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / p.shape[1] ** 0.5)   # HF's init std 0.02 would leave the blocks near-identity
+            elif "class_embedding" in k or "position" in k:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    return cfg, m
+
+
+@pytest.mark.parametrize("head_dim", [80, 64])
+def test_clip_vision_vs_transformers(backend, head_dim):
+    """head_dim 80 (ViT-H/14: per-head GEMM attention) and 64 (flash kernel) against transformers' CLIP vision tower."""
+    from pcdms_amd import CLIPVisionModelWithProjection
+    S = 28 if backend.is_emu else 224
+    cfg, hf = _hf_clip(dict(hidden_size=4 * head_dim, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4, image_size=S,
+                            patch_size=14, hidden_act="gelu", projection_dim=64), seed=11)
+    m = CLIPVisionModelWithProjection(cfg)
+    assert m.expected_shapes() == {k: tuple(v.shape) for k, v in hf.state_dict().items() if not k.endswith("position_ids")}
+    m.load_state_dict(hf.state_dict())
+    m.to(backend.device)
+    B = 1 if backend.is_emu else 2
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(12))
+    out = m(x.to(backend.device))
+    backend.sync()
+    with torch.no_grad():
+        ref = hf(x)
+    assert out.image_embeds.shape == ref.image_embeds.shape == (B, 64) and out.image_embeds.dtype == torch.float32
+    assert _rel(out.last_hidden_state, ref.last_hidden_state) <= 3e-2, _rel(out.last_hidden_state, ref.last_hidden_state)
+    assert _rel(out.image_embeds, ref.image_embeds) <= 3e-2, _rel(out.image_embeds, ref.image_embeds)
+    assert torch.equal(out["image_embeds"], out.image_embeds)   # the drivers index the output both ways
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 14, 14))
+
+
+def test_clip_vision_param_contract():
+    from pcdms_amd import CLIPVisionModelWithProjection
+    m = CLIPVisionModelWithProjection()   # defaults = OpenCLIP ViT-H/14 vision tower + projection
+    n = sum(torch.Size(s).numel() for s in m.expected_shapes().values())
+    assert 6.30e8 < n < 6.34e8   # 632 M
+    with pytest.raises(NotImplementedError):
+        CLIPVisionModelWithProjection(hidden_act="quick_gelu")

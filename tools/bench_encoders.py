@@ -11,7 +11,7 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from pcdms_amd import Dinov2Model, ImageProjModel_p  # noqa: E402
+from pcdms_amd import CLIPVisionModelWithProjection, Dinov2Model, ImageProjModel_p  # noqa: E402
 
 
 def main():
@@ -46,6 +46,29 @@ def main():
     wb = 2 * sum(v.numel() for k, v in sd.items() if "encoder.layer" in k)
     print(json.dumps(dict(metric="dinov2_giant_plus_image_proj_ms", value=ms, weight_GB=wb / 1e9, weight_stream_TBps=wb / (ms * 1e-3) / 1e12,
                           out_shape=list(y.shape), warm_s=setup)))
+    # ---- OpenCLIP ViT-H/14 vision tower + projection (image_encoder_g / stage-1 image_encoder), 632 M parameters
+    c = CLIPVisionModelWithProjection()
+    sd = {}
+    for k, shp in c.expected_shapes().items():
+        if len(shp) >= 2 and "position" not in k:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) / (shp[1] * (shp[2] * shp[3] if len(shp) == 4 else 1)) ** 0.5
+        elif k.endswith(".weight") and len(shp) == 1:
+            sd[k] = torch.ones(shp)
+        else:
+            sd[k] = torch.randn(shp, generator=g) * 0.02
+    c.load_state_dict(sd)
+    c.to("cuda")
+    t0 = time.time()
+    for _ in range(2):
+        e = c(x).image_embeds
+    torch.cuda.synchronize()
+    setup = time.time() - t0
+    e0.record()
+    for _ in range(10):
+        e = c(x).image_embeds
+    e1.record()
+    e1.synchronize()
+    print(json.dumps(dict(metric="clip_vit_h14_image_embeds_ms", value=e0.elapsed_time(e1) / 10, out_shape=list(e.shape), warm_s=setup)))
 
 
 if __name__ == "__main__":
