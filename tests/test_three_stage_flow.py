@@ -1,0 +1,122 @@
+"""From pixels to pixels through all three stages with the objects of the reference's three drivers, small models
+(stage1_batchtest_prior_model.py:80-113, stage2_batchtest_inpaint_model.py:150-200, stage3_batchtest_refined_model.py):
+
+  source image --CLIP vision--> s_img_embed --stage-1 prior (UnCLIP)--> pred_t_img_embed
+  source image --DINOv2--> ImageProjModel_p --> s_img_proj_f ;  pose canvas --ControlNetConditioningEmbedding--> st_pose_f
+  [source | black] canvas --VAE encode--> masked latents ;  stage-2 sampling ;  VAE decode --> uint8 canvases
+  generated target --VAE encode--> stage-3 refinement --> VAE decode
+
+The HIP chain is compared end to end with the same chain through the CPU oracles (transformers for the two encoders).
+Stated tolerance for this deep composition (encoders + 3 samplers + 3 VAE passes in bf16): rel-L2 <= 6e-2 on the stage-2
+and stage-3 latents, uint8 pixels mean abs diff <= 3 levels.
+"""
+from __future__ import annotations
+
+import pytest
+import torch
+
+pytest.importorskip("transformers")
+
+
+@pytest.mark.gpu
+def test_three_stage_flow(gpu_backend):
+    import pcdms_amd as P
+    from oracle import cond as OC
+    from oracle import prior as OP
+    from oracle import vae as OV
+    from oracle.pipeline import stage2_sample, stage3_sample
+    from oracle.schedulers import DDIMOracle, UnCLIPOracle
+    from oracle.unet import UNetConfig, synth_state_dict
+    from tests.test_encoders import _hf, _hf_clip
+    from tests.test_schedulers import SD21
+    from tests.test_unet import _kwargs
+    dev = gpu_backend.device
+    g = torch.Generator().manual_seed(0)
+    Himg, Wimg = 128, 64                       # one person image; canvas = [source | target] 128 x 128 -> latent 16 x 16
+    s_img = torch.rand(1, 3, Himg, Wimg, generator=g) * 2 - 1
+    pose = torch.rand(1, 3, Himg, 2 * Wimg, generator=g) * 2 - 1
+    pix224 = torch.randn(1, 3, 224, 224, generator=g)          # what CLIPImageProcessor would hand to both encoders
+    s_kp, t_kp = torch.rand(1, 1, 36, generator=g), torch.rand(1, 1, 36, generator=g)
+
+    # ---- models (seeded random weights), HIP + oracle twins
+    ccfg, hf_clip = _hf_clip(dict(hidden_size=320, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4, image_size=224,
+                                  patch_size=14, hidden_act="gelu", projection_dim=1024), seed=1)
+    dcfg, hf_dino = _hf(dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, mlp_ratio=4, use_swiglu_ffn=True,
+                             image_size=518, patch_size=14), seed=2)
+    clip = P.CLIPVisionModelWithProjection(ccfg); clip.load_state_dict(hf_clip.state_dict()); clip.to(dev)
+    dino = P.Dinov2Model(dcfg); dino.load_state_dict(hf_dino.state_dict()); dino.to(dev)
+    pcfg = OP.PriorConfig.tiny()
+    psd = OP.synth_state_dict(pcfg, 3)
+    prior = P.Stage1_PriorTransformer(num_attention_heads=2, num_layers=2, embedding_dim=1024, num_embeddings=2)
+    prior.load_state_dict(psd); prior.to(dev)
+    ucfg = UNetConfig.tiny(cross_attention_dim=1024, projection_class_embeddings_input_dim=1024)   # ctx = [DINO tokens | prior embed]
+    usd = synth_state_dict(ucfg, seed=4, random_affine=True)
+    unet2 = P.Stage2_InapintUNet2DConditionModel(**_kwargs(ucfg)); unet2.load_state_dict(usd); unet2.to(dev)
+    u3cfg = UNetConfig.tiny(in_channels=8, cross_attention_dim=1024, class_embed_type=None, projection_class_embeddings_input_dim=None)
+    u3sd = synth_state_dict(u3cfg, seed=5, random_affine=True)
+    unet3 = P.UNet2DConditionModel(**_kwargs(u3cfg)); unet3.load_state_dict(u3sd); unet3.to(dev)
+    vcfg = OV.VAEConfig.tiny()
+    vsd = OV.synth_state_dict(vcfg, 6)
+    vae = P.AutoencoderKL(block_out_channels=vcfg.block_out_channels); vae.load_state_dict(vsd); vae.to(dev)
+    ipsd = OC.synth(OC.image_proj_param_shapes(128, 64, ucfg.cross_attention_dim), seed=7, gain=1.0)
+    iproj = P.ImageProjModel_p(128, 64, ucfg.cross_attention_dim); iproj.load_state_dict(ipsd); iproj.to(dev)
+    posd = OC.synth(OC.pose_param_shapes(ucfg.block_out_channels[0], 3, (16, 32, 96, 256)), seed=8)
+    pose_proj = P.ControlNetConditioningEmbedding(ucfg.block_out_channels[0], 3, (16, 32, 96, 256)); pose_proj.load_state_dict(posd); pose_proj.to(dev)
+
+    # ---- injected randomness (the reference draws these from its generator)
+    s1_lat = torch.randn(1, 1024, generator=g)
+    s1_noise = [torch.randn(1, 1024, generator=g) for _ in range(4)]
+    h, w = Himg // 8, 2 * Wimg // 8
+    post_noise = torch.randn(1, 4, h, w, generator=g)
+    s2_lat = torch.randn(2, 4, h, w, generator=g)
+    post_noise3 = torch.randn(1, 4, h, w, generator=g)
+    s3_lat = torch.randn(1, 4, h, w, generator=g)
+    canvas = torch.cat([s_img, -torch.ones_like(s_img)], dim=3)                      # [source | black]
+
+    # ======== oracle chain (CPU fp32)
+    with torch.no_grad():
+        o_embed = hf_clip(pix224).image_embeds.unsqueeze(1)
+        o_feat = OC.image_proj_p(ipsd, hf_dino(pix224).last_hidden_state)
+    o_pred = OP.stage1_sample(psd, pcfg, UnCLIPOracle(), s_embed=o_embed, s_pose=s_kp, t_pose=t_kp, latents=s1_lat, noises=s1_noise,
+                              num_inference_steps=4, guidance_scale=0).unsqueeze(1)
+    o_pose = OC.pose_embedding(posd, pose)
+    o_ml = OV.sample_latents(OV.encode_moments(vsd, vcfg, canvas), post_noise) * vcfg.scaling_factor
+    o_lat2 = stage2_sample(usd, ucfg, DDIMOracle(), masked_latents=o_ml, s_img_proj_f=o_feat, st_pose_f=o_pose, pred_t_img_embed=o_pred,
+                           latents=s2_lat, num_images_per_prompt=2, guidance_scale=2.0, num_inference_steps=4)
+    o_img2 = OV.decode(vsd, vcfg, o_lat2 / vcfg.scaling_factor)
+    o_gl = OV.sample_latents(OV.encode_moments(vsd, vcfg, o_img2[:1].clamp(-1, 1)), post_noise3) * vcfg.scaling_factor
+    o_lat3 = stage3_sample(u3sd, u3cfg, DDIMOracle(), gen_t_img_latents=o_gl, s_img_proj_f=o_feat, latents=s3_lat, num_images_per_prompt=1,
+                           guidance_scale=2.0, num_inference_steps=3)
+    o_u8 = OV.postprocess_uint8(OV.decode(vsd, vcfg, o_lat3 / vcfg.scaling_factor))
+
+    # ======== HIP chain (the drivers' call sequence)
+    rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()  # noqa: E731
+    s_embed = clip(pix224.to(dev)).image_embeds.unsqueeze(1)
+    pipe1 = P.Stage1_PriorPipeline(prior).to(dev)
+    pred = pipe1(s_embed=s_embed, s_pose=s_kp.to(dev), t_pose=t_kp.to(dev), num_images_per_prompt=1, num_inference_steps=4,
+                 latents=s1_lat.to(dev), guidance_scale=0, variance_noises=s1_noise)[0].unsqueeze(1)
+    assert rel(pred, o_pred) <= 3e-2, rel(pred, o_pred)
+    feat = iproj(dino(pix224.to(dev)).last_hidden_state)
+    st_pose_f = pose_proj(pose.to(dev))
+    assert rel(feat, o_feat) <= 3e-2 and rel(st_pose_f, o_pose) <= 3e-2
+
+    class _FixedNoiseVAE:   # vae.encode(...).latent_dist.sample(generator) with the injected posterior noise
+        def __init__(self, noise):
+            self.noise, self.config = noise, vae.config
+            self.decode, self.decode_to_uint8 = vae.decode, vae.decode_to_uint8
+
+        def encode(self, x):
+            d = vae.encode(x).latent_dist
+            n = self.noise
+            return type("E", (), {"latent_dist": type("D", (), {"sample": staticmethod(lambda generator=None: d.sample(noise=n.to(dev)))})})
+    pipe2 = P.Stage2_InpaintDiffusionPipeline(unet2, P.DDIMScheduler.from_config(SD21), vae=_FixedNoiseVAE(post_noise))
+    out2 = pipe2(height=Himg, width=2 * Wimg, vae_image=canvas.to(dev), s_img_proj_f=feat, st_pose_f=st_pose_f, pred_t_img_embed=pred,
+                 latents=s2_lat.to(dev), num_images_per_prompt=2, guidance_scale=2.0, num_inference_steps=4, output_type="pt")
+    assert rel(out2.latents, o_lat2) <= 6e-2, rel(out2.latents, o_lat2)
+    gen_t = out2.images[:1] * 2 - 1             # "pt" output is the denormalised image in [0, 1]
+    pipe3 = P.Stage3_RefinedDiffusionPipeline(unet3, P.DDIMScheduler.from_config(SD21), vae=_FixedNoiseVAE(post_noise3))
+    out3 = pipe3(height=Himg, width=2 * Wimg, vae_gen_t_image=gen_t, s_img_proj_f=feat, latents=s3_lat.to(dev), num_images_per_prompt=1,
+                 guidance_scale=2.0, num_inference_steps=3, output_type="uint8")
+    assert rel(out3.latents, o_lat3) <= 6e-2, rel(out3.latents, o_lat3)
+    d = (out3.images.cpu().int() - o_u8.int()).abs().float()
+    assert out3.images.shape == (1, Himg, 2 * Wimg, 3) and d.mean() <= 3.0, d.mean()
