@@ -43,7 +43,8 @@ int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const flo
  *  A (bf16), one of
  *    linear : A[m, k] = (k < c1 ? a[m*lda + k] : a2[m*lda2 + k - c1])      (Linear, 1x1 conv, skip concat)
  *    conv3x3: m = (b, oy, ox) over [B, Ho, Wo]; k = (ky*3+kx)*cin + c; pad 1 (or no_pad_lo); stride 1|2;
- *             upsample=1 reads a[b, iy>>1, ix>>1, c] (nearest x2 folded in: Upsample2D, K5)
+ *             upsample=1 reads a[b, iy*Hi/Ho, ix*Wi/Wo, c] (nearest interpolation to Ho x Wo folded in -- iy>>1, ix>>1 for the
+ *             usual x2: Upsample2D, K5; other sizes: diffusers' upsample_size path for latents not divisible by 8)
  *  W: packed bf16 [Npad, K] (K contiguous; rows >= N zero).  K % 64 == 0, Npad % 64 == 0.
  *  epilogue: + bias[n] + rowvec[m / rows_per_batch, n] + residual[(m % res_mod), n]  then
  *    PCDM_EPI_STORE   : out[m*ldo + n]                                bf16

@@ -321,7 +321,9 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
                 x = transformer_2d(sd, f"up_blocks.{i}.attentions.{j}.", x, encoder_hidden_states, rheads[i], G)
             tap(f"up{i}.{j}", x)
         if i != len(boc) - 1:
-            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            # ref :625-633,796-799: when the latent size is not a multiple of 2**num_upsamplers the reference forwards
+            # upsample_size = the next skip's spatial size and Upsample2D interpolates to it instead of x2
+            x = F.interpolate(x, size=tuple(skips[-1].shape[-2:]), mode="nearest")
             x = F.conv2d(x, sd[f"up_blocks.{i}.upsamplers.0.conv.weight"],
                          sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
     # 6. post-process (ref :817-820)

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             a_b[j] = b; a_y[j] = y; a_x[j] = x;
             // offset of tap (0,0) relative to a descriptor base shifted back by (Wi+1) pixels (see rs_a below)
             a_off[j] = (uint32_t)((((int64_t)b * p.Hi + y * p.stride) * p.Wi + x * p.stride) * p.cin * 2) + ck;
-            const int Hv_ = p.Hi << p.upsample, Wv_ = p.Wi << p.upsample;
+            const int Hv_ = p.upsample ? p.Ho : p.Hi, Wv_ = p.upsample ? p.Wo : p.Wi;   // (virtual) input extent
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 const int iy = y * p.stride + tp / 3 - p.pad, ix = x * p.stride + tp % 3 - p.pad;
@@ -184,10 +184,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < AI; ++j)
                     buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? a_off[j] : kOOB, soff, as + j * 8 * BK);
-            } else {   // nearest-x2 upsample folded in: source pixel (iy>>1, ix>>1), not affine in the tap
+            } else {   // nearest upsample folded in (F.interpolate(mode="nearest") to Ho x Wo, then the conv): source pixel
+                       // floor(v * Hi / Ho) -- v >> 1 for the usual x2 -- not affine in the tap
+                const bool x2 = p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi;
 #pragma unroll
                 for (int j = 0; j < AI; ++j) {
-                    const int iy = (a_y[j] + ky - 1) >> 1, ix = (a_x[j] + kx - 1) >> 1;
+                    const int vy = a_y[j] + ky - 1, vx = a_x[j] + kx - 1;
+                    const int iy = x2 ? vy >> 1 : (vy > 0 ? vy * p.Hi / p.Ho : 0), ix = x2 ? vx >> 1 : (vx > 0 ? vx * p.Wi / p.Wo : 0);
                     const uint32_t ck = (uint32_t)(spos ^ ((((wave * AI + j) * 8 + srow) >> 1) & 7)) * 16u;
                     const uint32_t off = (uint32_t)((((int64_t)a_b[j] * p.Hi + iy + 1) * p.Wi + ix + 1) * p.cin * 2) + ck;
                     buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? off : kOOB, (uint32_t)(c0 * 2), as + j * 8 * BK);
@@ -606,7 +609,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     }
     if (p->conv) {
         if (p->cin % BK || p->K != 9 * p->cin || (p->stride != 1 && p->stride != 2) || p->a2) return -1;
-        if (p->upsample && (p->stride != 1 || p->no_pad_lo)) return -1;
+        if (p->upsample && (p->stride != 1 || p->no_pad_lo || p->Ho < p->Hi || p->Wo < p->Wi)) return -1;
         if (p->M != p->B * p->Ho * p->Wo) return -1;
     } else {
         if (p->a2 && (p->c1 % BK || p->c1 <= 0 || p->c1 >= p->K)) return -1;

@@ -379,8 +379,8 @@ class Stage2_InapintUNet2DConditionModel:
         if sample.dim() != 4 or sample.shape[1] != self.config.in_channels:
             raise ValueError(f"sample must be [B,{self.config.in_channels},h,w], got {tuple(sample.shape)}")
         B, _, h, w = sample.shape
-        if any(s % (2 ** self.num_upsamplers) for s in (h, w)):
-            raise NotImplementedError("latent height/width must be multiples of 2**num_upsamplers (ref :625-633)")
+        # latent sizes that are not multiples of 2**num_upsamplers (e.g. the stage-3 latent 64x44): the reference forwards the
+        # skip's size to Upsample2D (ref :625-633,796-799); here the upsampling conv gathers to the next skip's size
         if self._w is None:
             self._pack()
         if sample.device != self._device:
@@ -528,10 +528,11 @@ class Stage2_InapintUNet2DConditionModel:
                 if typ == "CrossAttnUpBlock2D":
                     x = transformer(f"up_blocks.{i}.attentions.{j}.", x, hh * ww, "u" if j % 2 else "ub")
             if i != nlev - 1:
+                ho, wo = skips[-1][1], skips[-1][2]      # = (2 hh, 2 ww) unless a down conv rounded an odd size up
                 x = ops.gemm(x.view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
-                             self._buf("us", (B * 4 * hh * ww, rev[i])),
-                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=2 * hh, Wo=2 * ww, upsample=1))
-                hh, ww = 2 * hh, 2 * ww
+                             self._buf("us", (B * ho * wo, rev[i])),
+                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, upsample=1))
+                hh, ww = ho, wo
         # ---- 6. post-process (ref :817-820)
         ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
         n = ops.groupnorm(x, None, B, HW, G, eps, W["norm_out"][0], W["norm_out"][1], True, self._buf("gn", (B * HW, boc[0])), ws)

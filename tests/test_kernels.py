@@ -220,13 +220,13 @@ def test_gemm_narrow_tiles_geglu_and_conv(backend):
         close(out.view(B, H, W, Cout), ref)
 
 
-@pytest.mark.parametrize("mode", ["s1", "s2", "up"])
+@pytest.mark.parametrize("mode", ["s1", "s2", "up", "up_size"])
 def test_conv3x3(backend, mode):
     dev = backend.device
     if backend.is_emu:
         B, H, W, Cin, Cout = 2, 6, 5, 64, 64
     else:
-        B, H, W, Cin, Cout = (8, 32, 44, 640, 640) if mode != "up" else (8, 16, 22, 1280, 1280)
+        B, H, W, Cin, Cout = (8, 32, 44, 640, 640) if mode not in ("up", "up_size") else (8, 16, 22, 1280, 1280)
     x = rnd(B, Cin, H, W, seed=50)
     w = rnd(Cout, Cin, 3, 3, seed=51, scale=1 / math.sqrt(9 * Cin))
     bias = torch.randn(Cout, generator=torch.Generator().manual_seed(52))
@@ -237,9 +237,12 @@ def test_conv3x3(backend, mode):
     elif mode == "s2":
         Ho, Wo, st, up = (H - 1) // 2 + 1, (W - 1) // 2 + 1, 2, 0
         ref = F.conv2d(x.float(), w.float(), bias, stride=2, padding=1)
-    else:
+    elif mode == "up":
         Ho, Wo, st, up = 2 * H, 2 * W, 1, 1
         ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1)
+    else:   # Upsample2D(output_size=skip size): latents not divisible by 2**num_upsamplers (odd skip sizes)
+        Ho, Wo, st, up = 2 * H - 1, 2 * W - 1, 1, 1
+        ref = F.conv2d(F.interpolate(x.float(), size=(Ho, Wo), mode="nearest"), w.float(), bias, padding=1)
     pw = ops.pack_conv3x3(w.float(), bias, dev)
     temb = torch.randn(B, Cout, generator=torch.Generator().manual_seed(53))
     out = torch.empty(B * Ho * Wo, Cout, dtype=BF16, device=dev)

@@ -106,6 +106,15 @@ def test_unet_tiny(backend):
 
 
 @pytest.mark.gpu
+def test_unet_latent_not_divisible_by_8(gpu_backend):
+    """Latent 20x11 (like the stage-3 latent 64x44 of a 352-wide image): the stride-2 convs round up (11 -> 6 -> 3 -> 2) and
+    the up path interpolates to each skip's size (ref :625-633 forward_upsample_size) instead of x2."""
+    cfg = UNetConfig.tiny()
+    m, out, ref, _ = _run(gpu_backend, cfg, 2, 20, 11, 7)
+    _check(out, ref)
+
+
+@pytest.mark.gpu
 def test_unet_full_size_config1(gpu_backend):
     """Full 868.9 M-parameter topology at config 1's latent 32x64 (256x256 pair), UNet batch 2."""
     cfg = UNetConfig()
