@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""flash_attn_kernel timing on the attention shapes of the stage-2 UNet (UNet batch 8, latent 64x88)."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from pcdms_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+B = 8
+for (H, Lq, Lk) in [(5, 5632, 5632), (10, 1408, 1408), (20, 352, 352), (5, 5632, 258), (10, 1408, 258)]:
+    C = H * 64
+    q = torch.randn(B * Lq, C, device=dev).to(torch.bfloat16)
+    k = torch.randn(B * Lk, C, device=dev).to(torch.bfloat16)
+    vt = torch.randn(B, C, (Lk + 7) // 8 * 8, device=dev).to(torch.bfloat16)
+    out = torch.empty(B * Lq, C, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        ops.flash_attn(q, k, vt, out, B, H, Lq, Lk)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.flash_attn(q, k, vt, out, B, H, Lq, Lk)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"attn B{B} H{H} Lq{Lq} Lk{Lk}: {us:8.1f} us  {4.0 * B * H * Lq * Lk * 64 / us / 1e6:7.1f} TF/s", flush=True)
