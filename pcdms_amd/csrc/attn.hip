@@ -100,14 +100,27 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
         f32x16 s[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
+        // all 8 K fragments first (8 ds_read_b128 in flight), then the 8 MFMAs: left alone, hipcc pairs every MFMA with its own
+        // ds_read + s_waitcnt and exposes one LDS latency per MFMA
+        u16x8 kfr[4][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int kf = 0; kf < 2; ++kf) {
-                const u16x8 kfrag = *(const u16x8*)&KV[cur][0][(kf * 32 + pi) * 64 + (((ks * 2 + hh) ^ sw_k) * 8)];
-                s[kf] = mfma_32x32x16(kfrag, qf[ks], s[kf]);
-            }
-        }
+            for (int kf = 0; kf < 2; ++kf)
+                kfr[ks][kf] = *(const u16x8*)&KV[cur][0][(kf * 32 + pi) * 64 + (((ks * 2 + hh) ^ sw_k) * 8)];
+        PCDM_SCHED_BARRIER();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(kfr[ks][kf], qf[ks], s[kf]);
+        // the V^T fragments of this tile are requested now, so that their LDS latency hides behind the softmax VALU work
+        u16x8 vfr[4][2];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+                vfr[s4][df] = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
+        PCDM_SCHED_BARRIER();
         // lane holds: s[kf][r] = score(query col, key key0 + 32kf + 16(r>>3) + 8hh + (r&7))
         if (key0 + KB > Lk) {
 #pragma unroll
@@ -144,10 +157,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-            for (int df = 0; df < 2; ++df) {
-                const u16x8 vfrag = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
-                oacc[df] = mfma_32x32x16(vfrag, pf[s4], oacc[df]);
-            }
+            for (int df = 0; df < 2; ++df) oacc[df] = mfma_32x32x16(vfr[s4][df], pf[s4], oacc[df]);
             lacc = mfma_32x32x16(ones, pf[s4], lacc);
         }
     };
