@@ -510,7 +510,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = STAGES * (BM + BN) * BK * (int)sizeof(u16);
+    // operand ring, or the wave-private fp32 epilogue tiles (32 x (WN + 4) floats per wave) if those need more
+    constexpr int smem_ops = STAGES * (BM + BN) * BK * (int)sizeof(u16);
+    constexpr int smem_epi = WGM * WGN * 32 * (BN / WGN + 4) * (int)sizeof(float);
+    constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG>,
@@ -557,6 +560,9 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         case 16: return launch_gemm<512, 64, 8, 1, 2, CONV>(a, st);   // 8 waves, 144 KiB, 1 block / CU
         // 256x256: 8 waves x (128x64): 32 MFMAs per wave per K-tile for the same 8 LDS-DMA instructions (1:4 instead of 1:2.7)
         case 17: return launch_gemm<256, 256, 2, 4, 2, CONV>(a, st);  // 8 waves, 128 KiB, 1 block / CU; N % 256 == 0
+        // 128x128 with EIGHT waves (32x64 each): the same 64 KiB and 2 blocks / CU as tile 4, but 4 waves per SIMD to hide
+        // LDS / MFMA-result latency (the 4-wave tiles run 2 waves per SIMD)
+        case 18: return launch_gemm<128, 128, 4, 2, 2, CONV>(a, st);
         default: return -1;
     }
 }
@@ -619,7 +625,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     hipStream_t st = (hipStream_t)s;
     int tile = p->tile & 0xff;
     const bool n128 = p->Npad % 128 == 0;
-    const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11;
+    const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11 || tile == 18;
     if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile
     if (tile == 0) {
         const int64_t t256 = (int64_t)((p->M + 255) / 256) * (p->Npad / 128);

@@ -194,7 +194,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
                a2 is not None, residual is not None)   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
         if tile == 0 and not torch.cuda.is_current_stream_capturing():
-            tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device)
+            tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device, out)
     elif split_k > 1:
         split = split_k
     p.tile = tile
@@ -215,7 +215,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
 # gemm.hip dispatch_tile(): id -> (BM, BN)
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),
-               15: (128, 64), 16: (512, 64), 17: (256, 256)}
+               15: (128, 64), 16: (512, 64), 17: (256, 256), 18: (128, 128)}
 _TUNED: dict = {}
 _WS: dict = {}
 
@@ -234,13 +234,14 @@ TUNE_ITERS = 3     # timed launches per candidate (tools/tune_gemm_shapes.py rai
 TUNE_REPEATS = 1
 
 
-def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int, device):
+def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int, device, out: Optional[torch.Tensor] = None):
     """Time every valid (tile configuration, split-K factor) of gemm.hip on this exact problem (HIP events on
     the launch stream, 1 warm + TUNE_ITERS timed launches each, best of TUNE_REPEATS) and return the fastest.
     Runs once per problem shape, outside graph capture; the launches are idempotent (same inputs, same output)."""
     fn = _lib.lib().pcdm_gemm
     nkt = pw.K // 64
     best, best_t = (0, 1), float("inf")
+    ref = None   # output of the first valid configuration: a candidate that disagrees with it is never selected
     for tile, (bm, bn) in TILE_SHAPES.items():
         ntiles = -(-p.M // bm) * (pw.Npad // bn if pw.Npad % bn == 0 else 0)
         if ntiles == 0:
@@ -257,6 +258,12 @@ def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int, device):
                 p.split_k, p.ws, p.ws_floats = 0, None, 0
             if fn(C.byref(p), stream) != 0:   # configuration not valid for this N / epilogue
                 break
+            if out is not None:
+                cur = out.float()
+                if ref is None:
+                    ref = cur.clone()
+                elif not bool(((cur - ref).abs().max() <= 2e-2 * ref.abs().max() + 1e-3).item()):
+                    continue
             t = float("inf")
             for _ in range(TUNE_REPEATS):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

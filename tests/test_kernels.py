@@ -92,9 +92,9 @@ def _gemm_sizes(backend):
                 (150, 192, 64, 6), (140, 256, 128, 7), (90, 320, 64, 8), (260, 192, 128, 9), (100, 256, 64, 10),
                 (300, 320, 128, 11), (270, 64, 128, 11), (130, 128, 64, 12), (257, 448, 64, 12),
                 (300, 192, 64, 13), (280, 256, 128, 14), (150, 128, 64, 15), (600, 128, 64, 16),
-                (300, 128, 256, 17)]
+                (300, 128, 256, 17), (200, 192, 128, 18)]
     return [(45056, 320, 320, 0), (2816, 1280, 1280, 0), (704, 1280, 1280, 0), (11264, 640, 1920, 0),
-            (1000, 192, 320, 0), (999, 64, 128, 1), (999, 128, 128, 4)] + [(777, 2560, 640, t) for t in range(1, 17)] + [(2816, 1280, 1280, 17), (777, 640, 256, 17)]
+            (1000, 192, 320, 0), (999, 64, 128, 1), (999, 128, 128, 4)] + [(777, 2560, 640, t) for t in range(1, 17)] + [(2816, 1280, 1280, 17), (777, 640, 256, 17), (777, 2560, 640, 18)]
 
 
 def test_gemm_linear_bias_residual_rowvec(backend):
