@@ -31,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 
 FLOP_PER_IMAGE = 118.84e12        # 50 steps x 2 CFG rows x 1188.4 GFLOP (latent 64x88, L=258)
 FLOP_PER_ROW_FWD = 1188.4e9
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
@@ -237,6 +238,16 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
         fa = fam["flash_attn_kernel"]
         out["flash_attn_kernel"] = {"achieved": round(fa[1] / fa[2] / 1e12, 1), "launches": fa[0],
                                     "avg_launch_us": round(fa[2] / fa[0] * 1e6, 2)}
+    # the HBM-bound kernel families of the step against the 8 TB/s roof: algorithmic bytes = tensor read
+    # once + written once, same per-launch event timing
+    hbm = {}
+    for name in ("groupnorm", "layernorm"):
+        if name in fam:
+            f = fam[name]
+            hbm[name] = {"bound": "hbm", "achieved": round(f[1] / f[2] / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(f[1] / f[2] / 1e9 / PEAK_HBM_GBS, 4), "launches": f[0], "total_us": round(f[2] * 1e6, 1)}
+    if hbm:
+        out["hbm_bound_kernels"] = hbm
     return out
 
 

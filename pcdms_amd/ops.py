@@ -61,17 +61,31 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gro
     C2 = 0 if x2 is None else x2.shape[-1]
     _c(x1, BF16); _c(out, BF16); _c(gamma, torch.float32); _c(beta, torch.float32)
     assert ws.numel() >= _lib.lib().pcdm_groupnorm_ws_floats(B, C1 + C2)
+    log = LAUNCH_LOG is not None and x1.is_cuda
+    if log:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib.lib().pcdm_groupnorm(_ptr(x1), C1, _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
                                   int(silu), _ptr(out), _ptr(ws), _stream(x1))
     _chk(rc, "pcdm_groupnorm")
+    if log:   # algorithmic bytes: the tensor read once + written once
+        e1.record()
+        LAUNCH_LOG.append(("groupnorm", 2.0 * B * HW * (C1 + C2) * 2, e0, e1, (B, HW, C1 + C2)))
     return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
     rows, Cc = x.shape
     _c(x, BF16); _c(out, BF16)
+    log = LAUNCH_LOG is not None and x.is_cuda
+    if log:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _chk(_lib.lib().pcdm_layernorm(_ptr(x), _ptr(out), rows, Cc, eps, _ptr(gamma), _ptr(beta), _stream(x)),
          "pcdm_layernorm")
+    if log:
+        e1.record()
+        LAUNCH_LOG.append(("layernorm", 2.0 * rows * Cc * 2, e0, e1, (rows, Cc)))
     return out
 
 

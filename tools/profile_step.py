@@ -57,10 +57,10 @@ def main():
         agg[k][1] += flops
         agg[k][2] += a.elapsed_time(b) * 1e-3
     tot = sum(v[2] for v in agg.values())
-    print(f"eager step wall {e0.elapsed_time(e1):.2f} ms; timed MFMA launches {tot*1e3:.2f} ms in {len(log)} launches")
-    print(f"{'kernel':18s} {'shape (M,N,K,conv,tile) / (B,H,Lq,Lk)':46s} {'n':>3s} {'ms':>8s} {'%':>6s} {'TF/s':>8s}")
+    print(f"eager step wall {e0.elapsed_time(e1):.2f} ms; timed launches (GEMM / attention / GroupNorm / LayerNorm) {tot*1e3:.2f} ms in {len(log)} launches")
+    print(f"{'kernel':18s} {'shape (M,N,K,conv,tile) / (B,H,Lq,Lk)':46s} {'n':>3s} {'ms':>8s} {'%':>6s} {'TF/s|TB/s':>10s}")
     for (name, info), (n, fl, t) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-        print(f"{name:18s} {str(info):46s} {n:3d} {t*1e3:8.3f} {100*t/tot:6.1f} {fl/t/1e12:8.1f}")
+        print(f"{name:18s} {str(info):46s} {n:3d} {t*1e3:8.3f} {100*t/tot:6.1f} {fl/t/1e12:10.2f}")
 
 
 if __name__ == "__main__":
