@@ -387,6 +387,67 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const u16* __restri
     }
 }
 
+// LayerNorm with LPR lanes per row and OPL octets per lane (C = 8 * LPR * OPL): a wave normalises 64 / LPR rows at once, every
+// lane is busy (the one-wave-per-row kernel above idles 24 of 64 lanes at C = 320) and has OPL independent 16-byte loads in
+// flight; the LPR lanes of a row read consecutive octets (128-byte runs), reductions are log2(LPR) xor-shuffles.
+template <int LPR, int OPL>
+__global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const u16* __restrict__ x, u16* __restrict__ y, int rows,
+                                                                float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta) {
+    constexpr int RPW = 64 / LPR, C = 8 * LPR * OPL;
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int row = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool valid = row < rows;   // keep whole waves alive for the shuffles
+    const int64_t base = (int64_t)(valid ? row : 0) * C;
+    u16x8 u[OPL];
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) u[j] = *(const u16x8*)(x + base + (j * LPR + sub) * 8);
+    float v[OPL][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < OPL; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[j][e] = bf2f(u[j][e]);
+            s += v[j][e];
+        }
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < OPL; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = v[j][e] - mean;
+            q += d * d;
+        }
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int c = (j * LPR + sub) * 8;
+        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = f2bf((v[j][e] - mean) * rstd * g0[e] + b0[e]);
+            o[e + 4] = f2bf((v[j][e + 4] - mean) * rstd * g1[e] + b1[e]);
+        }
+        *(u16x8*)(y + base + c) = o;
+    }
+}
+
+template <int LPR, int OPL>
+void launch_layernorm_rows(hipStream_t st, const u16* x, u16* y, int rows, float eps, const float* gamma, const float* beta) {
+    constexpr int rpb = (kThreads / 64) * (64 / LPR);
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(layernorm_rows_kernel<LPR, OPL>), dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, x, y, rows, eps,
+                gamma, beta);
+}
+
 inline int gn_chunks(int HW, int rows_par) {
     int n = (HW + rows_par * kGnUnroll - 1) / (rows_par * kGnUnroll);
     if (n > kGnMaxChunks) n = kGnMaxChunks;
@@ -450,12 +511,22 @@ extern "C" int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps
                               const float* beta, pcdm_stream_t s) {
     if (!x || !y || rows <= 0 || C % 8 || C > 4096 || C <= 0) return -1;
     const int rpb = kThreads / 64;
-    if (C <= 1536) {
-        PCDM_LAUNCH(layernorm_kernel<3>, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, (hipStream_t)s, (const u16*)x,
-                    (u16*)y, rows, C, eps, gamma, beta);
-    } else {
-        PCDM_LAUNCH(layernorm_kernel<8>, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, (hipStream_t)s, (const u16*)x,
-                    (u16*)y, rows, C, eps, gamma, beta);
+    hipStream_t st = (hipStream_t)s;
+    const u16* xi = (const u16*)x;
+    u16* yo = (u16*)y;
+    switch (C) {   // widths of the UNet (320 / 640 / 1280), DINOv2 (1536), the prior (2048), ImageProjModel_p (768)
+        case 320: launch_layernorm_rows<8, 5>(st, xi, yo, rows, eps, gamma, beta); break;
+        case 640: launch_layernorm_rows<16, 5>(st, xi, yo, rows, eps, gamma, beta); break;
+        case 1280: launch_layernorm_rows<32, 5>(st, xi, yo, rows, eps, gamma, beta); break;
+        case 768: launch_layernorm_rows<32, 3>(st, xi, yo, rows, eps, gamma, beta); break;
+        case 1536: launch_layernorm_rows<64, 3>(st, xi, yo, rows, eps, gamma, beta); break;
+        case 2048: launch_layernorm_rows<64, 4>(st, xi, yo, rows, eps, gamma, beta); break;
+        default:
+            if (C <= 1536) {
+                PCDM_LAUNCH(layernorm_kernel<3>, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, xi, yo, rows, C, eps, gamma, beta);
+            } else {
+                PCDM_LAUNCH(layernorm_kernel<8>, dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, xi, yo, rows, C, eps, gamma, beta);
+            }
     }
     PCDM_CHECK_LAUNCH();
     return 0;

@@ -74,7 +74,8 @@ def test_groupnorm(backend, case):
 
 def test_layernorm(backend):
     dev = backend.device
-    for rows, C in ([(9, 64), (5, 320), (3, 2048)] if backend.is_emu else [(8 * 5632, 320), (2816, 1280), (703, 640), (12, 2048), (7, 4096)]):
+    for rows, C in ([(9, 64), (13, 320), (7, 640), (3, 1280), (5, 768), (2, 1536), (3, 2048)] if backend.is_emu else
+                    [(8 * 5632, 320), (2816, 1280), (703, 640), (12, 2048), (7, 4096), (257, 1536), (257, 768), (1001, 512)]):
         x = rnd(rows, C, seed=5) * 3 + 1
         gamma = torch.rand(C, generator=torch.Generator().manual_seed(6)) + 0.5
         beta = torch.randn(C, generator=torch.Generator().manual_seed(7))
