@@ -13,7 +13,10 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from pcdms_amd import ops  # noqa: E402
+from pcdms_amd import _lib, ops  # noqa: E402
+
+if len(sys.argv) > 1:   # A/B: an alternative build of the library
+    _lib.load(sys.argv[1])
 
 # (HW, C1, C2, instances per UNet forward)
 SHAPES = [(5632, 320, 0, 9), (5632, 640, 320, 1), (5632, 320, 320, 2), (5632, 640, 0, 0),
