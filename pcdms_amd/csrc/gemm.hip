@@ -490,7 +490,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     if (i >= (int64_t)p.M * nq) return;
     const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.split_k; ++s) v += *(const f32x4*)(p.ws + ((int64_t)s * p.M + m) * p.Npad + n);
+    // slabs summed in a fixed order, four independent 16-byte loads in flight at a time (a one-load-per-iteration loop
+    // pays one L2 / HBM round trip per slab)
+    const float* wp = p.ws + (int64_t)m * p.Npad + n;
+    const int64_t slab = (int64_t)p.M * p.Npad;
+    int s = 0;
+    for (; s + 4 <= p.split_k; s += 4) {
+        const f32x4 t0 = *(const f32x4*)(wp + (s + 0) * slab), t1 = *(const f32x4*)(wp + (s + 1) * slab);
+        const f32x4 t2 = *(const f32x4*)(wp + (s + 2) * slab), t3 = *(const f32x4*)(wp + (s + 3) * slab);
+        v += t0;
+        v += t1;
+        v += t2;
+        v += t3;
+    }
+    for (; s < p.split_k; ++s) v += *(const f32x4*)(wp + s * slab);
     if (p.bias) v += *(const f32x4*)(p.bias + n);
     if (p.rowvec) v += *(const f32x4*)(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n);
     if (p.act) {
