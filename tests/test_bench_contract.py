@@ -1,0 +1,48 @@
+"""bench.py output contract: the committed round-1 bench line (profiles/r1_bench.json, produced on an MI355X by `python bench.py`)
+carries every field the driver parses, and bench.py's flags / defaults are the ones the driver passes."""
+from __future__ import annotations
+
+import json
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = (ROOT / "profiles" / "r1_bench.json").read_text().strip().splitlines()[-1]
+    d = json.loads(line)
+    base = json.loads((ROOT / "BASELINE.json").read_text())
+    assert d["metric"].startswith("images/sec") and d["unit"] == "images/s" and base["metric"].startswith("images/sec")
+    for k, t in (("value", float), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float)):
+        assert isinstance(d[k], t) and d[k] > 0, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic"
+    cfg = d["config"]
+    assert "352x512" in cfg["workload"] and "batch=4" in cfg["workload"] and "50 DDIM" in cfg["workload"] and "model" not in cfg
+    # value is whole-job throughput: images = n_gpus * batch * steps over the timed region
+    assert abs(d["value"] - d["n_gpus"] * cfg["global_batch"] / d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    # achieved = algorithmic FLOPs per launch / average launch duration
+    assert abs(r["achieved"] - r["alg_gflop_per_launch"] / r["avg_launch_us"] * 1e3)   # GFLOP / us = 1000 TFLOP/s < 0.02 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_bench_flags_and_defaults():
+    src = (ROOT / "bench.py").read_text()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert f'"{flag}"' in src, flag
+    assert re.search(r'"--gpus", type=int, default=1', src)
+    for env in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        assert env in src
+    assert "dist.barrier()" in src and "torch.cuda.synchronize()" in src and "ReduceOp.MAX" in src
+    # the oracle is only the cpu_baseline leg / synthetic data generator, never the measured path
+    assert "from oracle.unet import unet_forward" in src.split("def cpu_baseline")[1]
+
+
+def test_entry_points_exist():
+    src = (ROOT / "__graft_entry__.py").read_text()
+    assert "def build(" in src and "def smoke(" in src and "gfx950" in (ROOT / "pcdms_amd" / "build.py").read_text()
