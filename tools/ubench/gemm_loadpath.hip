@@ -4,6 +4,8 @@
 //   mode 0: no global traffic (LDS-resident data)                       -- the ceiling
 //   mode 1: LDS-DMA (buffer_load_dwordx4 ... lds), what gemm.hip does
 //   mode 2: register-staged (buffer_load_dwordx4 -> VGPRs, later ds_write_b128)
+//   mode 3 / 4: LDS-DMA pieces spread over the four k-steps, issued after / before each k-step's MFMAs
+//   mode 5: LDS-DMA, 3-stage ring, two tiles in flight, counted s_waitcnt
 // The source (8 MiB, L2 / MALL resident) is read with per-lane constant offsets + an SGPR offset, like the real kernel.
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 -o gemm_loadpath gemm_loadpath.hip
 #include <hip/hip_runtime.h>
@@ -26,6 +28,7 @@ __device__ __forceinline__ f32x16 mfma(u16x8 a, u16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void wait_all_then_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm_then_barrier() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int NW, int MODE>
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
     constexpr int PIECES = ROWS / 8 / NW;       // 1 KiB pieces per wave per K-tile (8 rows x 128 B each)
     constexpr int STAGE = ROWS * 64;            // u16 elements per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u16* ring = (u16*)smem;                     // [2][ROWS][64]
+    u16* ring = (u16*)smem;                     // [2 or 3][ROWS][64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * STAGE; i += blockDim.x) ring[i] = (u16)(0x3f80 + (i & 7));
@@ -61,15 +64,36 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
             for (int j = 0; j < PIECES; ++j) regs[j] = load16(rs, voff[j], soff);
         }
     };
+    auto issue_piece = [&](int it, int stage, int j) {
+        const uint32_t soff = (uint32_t)((it * 8192) % (src_bytes / 2));
+        dma16(rs, voff[j], soff, ring + stage * STAGE + (wave * PIECES + j) * 512);
+    };
+    constexpr int NST = MODE == 5 ? 3 : 2;
     issue(0, 0);
+    if (MODE == 5) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) issue_piece(0, 0, j);
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) issue_piece(1, 1, j);
+    }
+    if (MODE == 3 || MODE == 4) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) issue_piece(0, 0, j);
+    }
     if (MODE == 2) {
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) *(u32x4*)(ring + (wave * PIECES + j) * 512 + lane * 8) = regs[j];
     }
-    int cur = 0;
+    int cur = 0, nxt = MODE == 5 ? 2 : 1;
     for (int it = 0; it < iters; ++it) {
-        wait_all_then_barrier();   // tile `it` is in LDS for everybody
-        issue(it + 1, cur ^ 1);
+        if (MODE == 5) wait_vm_then_barrier<PIECES>();   // tile `it` landed; tile it+1 stays in flight
+        else wait_all_then_barrier();                    // tile `it` is in LDS for everybody
+        if (MODE == 5) {
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) issue_piece(it + 2, nxt, j);
+        } else if (MODE != 3 && MODE != 4) {
+            issue(it + 1, nxt);
+        }
         const u16* as = ring + cur * STAGE + arow * 64;
         const u16* bs = ring + cur * STAGE + brow * 64;
 #pragma unroll
@@ -80,18 +104,26 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
             for (int j = 0; j < 2; ++j) xf[j] = *(const u16x8*)(as + j * 32 * 64 + co);
 #pragma unroll
             for (int i = 0; i < 2; ++i) wf[i] = *(const u16x8*)(bs + i * 32 * 64 + co);
+            if (MODE == 4) {
+#pragma unroll
+                for (int j = ks * PIECES / 4; j < (ks + 1) * PIECES / 4; ++j) issue_piece(it + 1, nxt, j);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = mfma(wf[i], xf[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma(wf[i], xf[j], acc[i][j]);
+            if (MODE == 3) {
+#pragma unroll
+                for (int j = ks * PIECES / 4; j < (ks + 1) * PIECES / 4; ++j) issue_piece(it + 1, nxt, j);
+            }
         }
         if (MODE == 2) {   // the fetched tile goes to the other stage (its readers finished before the barrier above)
             wait_vm0();
 #pragma unroll
-            for (int j = 0; j < PIECES; ++j) *(u32x4*)(ring + (cur ^ 1) * STAGE + (wave * PIECES + j) * 512 + lane * 8) = regs[j];
+            for (int j = 0; j < PIECES; ++j) *(u32x4*)(ring + nxt * STAGE + (wave * PIECES + j) * 512 + lane * 8) = regs[j];
         }
-        cur ^= 1;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
     float s = 0;
     for (int i = 0; i < 2; ++i)
@@ -104,7 +136,7 @@ template <int NW, int MODE>
 void run(int blocks_per_cu, const u16* src, uint32_t src_bytes, const char* name) {
     float* out;
     const int blocks = 256 * blocks_per_cu, iters = 2000;
-    constexpr int smem = 2 * (NW == 4 ? 256 : 384) * 128;
+    constexpr int smem = (MODE == 5 ? 3 : 2) * (NW == 4 ? 256 : 384) * 128;
     hipMalloc(&out, (size_t)blocks * NW * 64 * 4);
     hipFuncSetAttribute((const void*)k<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t e0, e1;
@@ -131,8 +163,13 @@ int main() {
     run<4, 0>(2, src, bytes, "128x128/4 waves, LDS-resident (ceiling)");
     run<4, 1>(2, src, bytes, "128x128/4 waves, LDS-DMA 8 x 1 KiB per wave per K-tile");
     run<4, 2>(2, src, bytes, "128x128/4 waves, register-staged (8 loads + 8 ds_write_b128)");
+    run<4, 3>(2, src, bytes, "128x128/4 waves, LDS-DMA spread over k-steps, after MFMAs");
+    run<4, 4>(2, src, bytes, "128x128/4 waves, LDS-DMA spread over k-steps, before MFMAs");
+    run<4, 5>(1, src, bytes, "128x128/4 waves, LDS-DMA 3 stages / 2 tiles in flight");
     run<8, 0>(1, src, bytes, "256x128/8 waves, LDS-resident (ceiling)");
     run<8, 1>(1, src, bytes, "256x128/8 waves, LDS-DMA 6 x 1 KiB per wave per K-tile");
     run<8, 2>(1, src, bytes, "256x128/8 waves, register-staged (6 loads + 6 ds_write_b128)");
+    run<8, 3>(1, src, bytes, "256x128/8 waves, LDS-DMA spread over k-steps, after MFMAs");
+    run<8, 5>(1, src, bytes, "256x128/8 waves, LDS-DMA 3 stages / 2 tiles in flight");
     return 0;
 }
