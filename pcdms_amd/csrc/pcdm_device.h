@@ -183,14 +183,22 @@ __device__ __forceinline__ float pcdm_load_agent(const float* p) {   // L2-serve
 
 // ---- wave reductions -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef PCDM_EMU
+    return emu_wave_reduce(v, false);   // one exchange instead of six (summation order differs from the butterfly in the last bits)
+#else
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef PCDM_EMU
+    return emu_wave_reduce(v, true);
+#else
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
+#endif
 }
 
 #define PCDM_CHECK_LAUNCH()                          \

@@ -64,6 +64,17 @@ template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
     memcpy(&r, all + ((emu::lane_id() ^ mask) & 63) * emu::kSlot, sizeof(T));
     return r;
 }
+// whole-wave reductions in ONE exchange (the butterfly of __shfl_xor steps costs log2(64) fiber round trips per lane)
+inline float emu_wave_reduce(float v, bool is_max) {
+    const char* all = emu::wave_exchange(&v, sizeof(float));
+    float acc = 0.f;
+    for (int l = 0; l < 64; ++l) {
+        float r;
+        memcpy(&r, all + l * emu::kSlot, sizeof(float));
+        acc = l == 0 ? r : (is_max ? (r > acc ? r : acc) : acc + r);
+    }
+    return acc;
+}
 template <class T> inline T __shfl(T v, int src, int width = 64) {
     const char* all = emu::wave_exchange(&v, sizeof(T));
     T r;
