@@ -72,10 +72,8 @@ class _Base:
 
     def __init__(self, **kwargs):
         cfg = dict(self._defaults)
-        for k, v in kwargs.items():
-            if k in cfg or k.startswith("_"):
-                cfg[k] = v  # from_config semantics: keys of other schedulers are ignored
-        self.config = _Config(**cfg)
+        cfg.update(kwargs)   # from_config semantics (diffusers): keys of other, compatible schedulers do not act here but stay in
+        self.config = _Config(**cfg)   # .config ("hidden" attributes), so that A.from_config(B.from_config(A.config).config) round-trips
         betas = _betas(self.config)
         self.betas = torch.from_numpy(betas.copy())
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)  # fp32, as diffusers
