@@ -57,6 +57,35 @@ class Stage2_InpaintDiffusionPipeline:
         self._graph_key = None
         self._st = {}
 
+    #: the stock UNet class a pipeline directory holds (the drivers replace ``pipe.unet`` right after ``from_pretrained``)
+    _unet_kwargs: dict = {}
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, **kwargs):
+        """``Stage2_InpaintDiffusionPipeline.from_pretrained(sd21_dir, torch_dtype=...)`` as the drivers call it
+        (/root/reference/stage2_batchtest_inpaint_model.py:123): loads ``vae/`` and ``unet/`` (stock SD UNet; the driver then
+        assigns its own ``pipe.unet`` / ``pipe.scheduler``, :125-132) and builds a scheduler from
+        ``scheduler/scheduler_config.json``.  SD-2.1 ships a PNDM config; PNDM is not part of this path, so any scheduler
+        class that is not implemented here becomes a ``DDIMScheduler`` with the shared keys (the drivers replace it anyway).
+        Text encoder / tokenizer / safety checker of the directory are not used by the stage-2 call and are not loaded."""
+        import json
+        from pathlib import Path
+
+        from . import schedulers as S
+        from .unet import UNet2DConditionModel
+        from .vae import AutoencoderKL
+        root = Path(str(pretrained_model_name_or_path))
+        vae = AutoencoderKL.from_pretrained(root, subfolder="vae", torch_dtype=torch_dtype) if (root / "vae").is_dir() else None
+        unet = UNet2DConditionModel.from_pretrained(root, subfolder="unet", torch_dtype=torch_dtype, **cls._unet_kwargs)
+        scfg = {}
+        sj = root / "scheduler" / "scheduler_config.json"
+        if sj.exists():
+            scfg = json.loads(sj.read_text())
+        sched_cls = getattr(S, str(scfg.get("_class_name", "")), None)
+        if not (isinstance(sched_cls, type) and issubclass(sched_cls, S._Base)):
+            sched_cls = S.DDIMScheduler
+        return cls(unet, sched_cls.from_config(scfg), vae=vae)
+
     @property
     def device(self):
         return self.unet.device
@@ -65,6 +94,8 @@ class Stage2_InpaintDiffusionPipeline:
 
     def to(self, device):
         self.unet.to(device)
+        if self.vae is not None and hasattr(self.vae, "to"):
+            self.vae.to(device)
         return self
 
     def enable_xformers_memory_efficient_attention(self, attention_op=None):
@@ -260,9 +291,10 @@ class Stage2_InpaintDiffusionPipeline:
         if st.get("gr", guidance_rescale) != guidance_rescale:
             self._graph = None
         st["gr"] = guidance_rescale
-        if st.get("w_gen") != getattr(unet, "_pack_gen", 0):   # weights were re-packed (load_state_dict / .to): re-capture
+        w_gen = (id(unet), getattr(unet, "_pack_gen", 0))
+        if st.get("w_gen") != w_gen:   # pipe.unet was replaced, or its weights re-packed (load_state_dict / .to): re-capture
             self._graph = None
-        st["w_gen"] = getattr(unet, "_pack_gen", 0)
+        st["w_gen"] = w_gen
         st["step"].zero_()
         self._st, self._graph_key = st, key
         simple_cb = callback is None

@@ -311,23 +311,40 @@ class Stage1_PriorPipeline:
     rows).  The reference draws the scheduler's variance noise from the global RNG (:478 passes no generator); here the
     pipeline's ``generator`` is used, or ``variance_noises`` (one [N, E] tensor per step) when given."""
 
-    def __init__(self, prior: Stage1_PriorTransformer, scheduler: Optional[UnCLIPScheduler] = None, image_encoder=None,
+    def __init__(self, prior: Optional[Stage1_PriorTransformer], scheduler: Optional[UnCLIPScheduler] = None, image_encoder=None,
                  image_processor=None):
         self.prior, self.image_encoder, self.image_processor = prior, image_encoder, image_processor
         self.scheduler = scheduler or UnCLIPScheduler(**UnCLIPScheduler.KANDINSKY22_PRIOR)
-        self._device = prior.device
+        self._to_device = prior.device if prior is not None else torch.device("cpu")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, **kwargs):
+        """``Stage1_PriorPipeline.from_pretrained(kandinsky_2_2_prior_dir)`` as the stage-1 driver calls it
+        (/root/reference/stage1_batchtest_prior_model.py:55): takes the scheduler from ``scheduler/scheduler_config.json``.
+        The directory's stock prior (embedding_dim 1280, 81 tokens) is not this model and is not loaded -- the driver assigns
+        ``pipe.prior`` on the next line (:56); the CLIP text / image towers of the directory are not used by this call."""
+        d = Path(str(pretrained_model_name_or_path)) / "scheduler" / "scheduler_config.json"
+        scfg = json.loads(d.read_text()) if d.exists() else dict(UnCLIPScheduler.KANDINSKY22_PRIOR)
+        return cls(None, UnCLIPScheduler.from_config(scfg))
 
     def to(self, device):
-        self.prior.to(device)
-        self._device = self.prior.device
+        self._to_device = torch.device(device)
+        for m in (self.prior, self.image_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(device)
         return self
 
     @property
     def device(self):
-        return self._device
+        return self.prior.device if self.prior is not None else self._to_device
+
+    @property
+    def _device(self):
+        return self.device
 
     def enable_xformers_memory_efficient_attention(self, attention_op=None):
-        self.prior.set_use_memory_efficient_attention_xformers(True, attention_op)
+        if self.prior is not None:
+            self.prior.set_use_memory_efficient_attention_xformers(True, attention_op)
 
     def prepare_latents(self, shape, dtype, device, generator, latents, scheduler):
         if latents is None:
