@@ -29,7 +29,7 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
 
 
 def build_conditioning(masked_latents, s_img_proj_f, st_pose_f, pred_t_img_embed, N: int, cfg_on: bool,
-                       mask=None, use_prior_embed: bool = True):
+                       mask=None, use_prior_embed: bool = True, uncond_feature=None):
     """ref :430-466: CFG-doubled conditioning for one pair.  Returns dict of fp32 tensors."""
     bs = s_img_proj_f.shape[0]
     assert bs == 1, "reference semantics hold for one pair per call (SURVEY.md Appendix C-1)"
@@ -47,7 +47,10 @@ def build_conditioning(masked_latents, s_img_proj_f, st_pose_f, pred_t_img_embed
         feature_f = s_img_proj_f.repeat(bs * N, 1, 1)
         prior_embed = None
     if cfg_on:
-        feature_f = torch.cat([torch.zeros_like(feature_f), feature_f], dim=0)
+        # ref :455-458: literal zeros; the notebook caller (src/pipelines/PCDMs_pipeline.py:1061-1062, pcdms_kaggle_demo.ipynb cell 37)
+        # passes negative_prompt_embeds = image_proj_model(zeros) instead: ``uncond_feature`` [1, L, D]
+        unc = torch.zeros_like(feature_f) if uncond_feature is None else uncond_feature.repeat(bs * N, 1, 1)
+        feature_f = torch.cat([unc, feature_f], dim=0)
         if prior_embed is not None:
             prior_embed = torch.cat([torch.zeros_like(prior_embed), prior_embed], dim=0)
     # NOTE ref :464-466 repeats feature_f a second time when CFG is off (only valid for N=1);
@@ -59,14 +62,14 @@ def stage2_sample(sd: Dict[str, torch.Tensor], cfg: UNetConfig, scheduler, *, ma
                   st_pose_f, pred_t_img_embed, latents, num_images_per_prompt: int = 4,
                   guidance_scale: float = 2.0, num_inference_steps: int = 50, guidance_rescale: float = 0.0,
                   mask=None, eps_hook: Optional[Callable] = None,
-                  unet: Optional[Callable] = None, use_prior_embed: bool = True) -> torch.Tensor:
+                  unet: Optional[Callable] = None, use_prior_embed: bool = True, uncond_feature=None) -> torch.Tensor:
     """Returns final latents [N,4,h,w] (before vae.decode, ref :528).
 
     ``unet(sample, t, encoder_hidden_states=, class_labels=, my_pose_cond=) -> eps`` may replace
     the oracle UNet (used to run the oracle loop on top of another UNet implementation)."""
     N = num_images_per_prompt
     cfg_on = guidance_scale > 1.0
-    c = build_conditioning(masked_latents, s_img_proj_f, st_pose_f, pred_t_img_embed, N, cfg_on, mask, use_prior_embed)
+    c = build_conditioning(masked_latents, s_img_proj_f, st_pose_f, pred_t_img_embed, N, cfg_on, mask, use_prior_embed, uncond_feature)
     scheduler.set_timesteps(num_inference_steps)
     latents = latents * scheduler.init_noise_sigma
     if unet is None:

@@ -5,7 +5,7 @@ Drop-in objects for the reference's ``pipe.unet`` / ``pipe.scheduler``
 ``pcdms_amd/lib/libpcdm.so`` (C-ABI: include/pcdm.h).  See DESIGN.md / INTEGRATION.md.
 """
 from .parallel import run_sharded, split_list_into_chunks  # noqa: F401
-from .pipeline import (Simple_Stage2_InpaintDiffusionPipeline, Stage2_InpaintDiffusionPipeline,  # noqa: F401
+from .pipeline import (PCDMsPipeline, Simple_Stage2_InpaintDiffusionPipeline, Stage2_InpaintDiffusionPipeline,  # noqa: F401
                        Stage2_InpaintDiffusionPipelineOutput, Stage3_RefinedDiffusionPipeline)
 from .schedulers import DDIMScheduler, DDPMScheduler, UnCLIPScheduler, UniPCMultistepScheduler  # noqa: F401
 from .unet import (Stage2_InapintUNet2DConditionModel, Stage2InpaintUNet, UNet2DConditionModel,  # noqa: F401

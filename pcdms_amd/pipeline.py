@@ -184,6 +184,17 @@ class Stage2_InpaintDiffusionPipeline:
         lat = self.prepare_latents(bs * N, 4, height, width, torch.float32, device, generator, latents).contiguous()
         extra = self.prepare_extra_step_kwargs(generator, eta)
 
+        lat = self._sample(lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, guidance_scale, guidance_rescale,
+                           eta, extra, mode, use_graph, callback, callback_steps)
+
+        images = self._postprocess(lat, output_type)
+        if not return_dict:
+            return (images, None)
+        return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
+
+    def _sample(self, lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, guidance_scale, guidance_rescale, eta,
+                extra, mode, use_graph, callback, callback_steps):
+        """The denoise loop on prepared (CFG-doubled) conditioning: fused + hipGraph for DDIM, the reference's literal loop otherwise."""
         linear = isinstance(self.scheduler, (DDIMScheduler, DDPMScheduler)) and eta == 0.0 \
             and not isinstance(self.scheduler, DDPMScheduler)
         mode = mode or ("fused" if linear else "reference")
@@ -213,10 +224,7 @@ class Stage2_InpaintDiffusionPipeline:
                                   float(guidance_scale), eta, use_graph, callback, callback_steps,
                                   float(guidance_rescale) if do_cfg else 0.0)
 
-        images = self._postprocess(lat, output_type)
-        if not return_dict:
-            return (images, None)
-        return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
+        return lat
 
     def _postprocess(self, lat, output_type):
         """ref :528-532: vae.decode(latents / scaling_factor) + VaeImageProcessor.postprocess."""
@@ -379,6 +387,70 @@ class Stage3_RefinedDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
             lat = self.scheduler.step(eps, t, lat, **extra, return_dict=False)[0]
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, lat)
+        images = self._postprocess(lat, output_type)
+        if not return_dict:
+            return (images, None)
+        return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
+
+
+class PCDMsPipeline(Simple_Stage2_InpaintDiffusionPipeline):
+    """The notebook's "simplified PCDMs" caller of the same UNet: mirrors
+    ``PCDMsPipeline.__call__`` (/root/reference/src/pipelines/PCDMs_pipeline.py:893-1184; pcdms_kaggle_demo.ipynb cell 38).
+    Inputs arrive as tensors: ``simg_mask_latents`` (VAE latents of the [source | black] canvas, already scaled), ``mask``,
+    ``cond_pose`` (the pose feature, un-doubled: it broadcasts over the batch, :1127), ``prompt_embeds`` = the projected
+    DINOv2 tokens and ``negative_prompt_embeds`` = ``image_proj_model(zeros)`` (cell 37) -- a NON-zero unconditional
+    context; no ``class_labels``.  The input is ``cat([latents, mask, simg_mask_latents], 1)`` doubled for CFG (:1117-1119),
+    which is what ``pcdm_assemble_input`` builds.  Text prompts, IP-adapter images, LoRA scale, ``clip_skip``, custom
+    ``timesteps`` and the safety checker are SD boilerplate the notebook never uses: ``NotImplementedError`` when given."""
+
+    @torch.no_grad()
+    def __call__(self, simg_mask_latents=None, mask=None, cond_pose=None, prompt=None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, timesteps=None, guidance_scale: float = 7.5,
+                 negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents: Optional[torch.Tensor] = None, prompt_embeds=None, negative_prompt_embeds=None, ip_adapter_image=None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True, cross_attention_kwargs=None,
+                 guidance_rescale: float = 0.0, clip_skip=None, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=("latents",), mode: Optional[str] = None, use_graph: bool = True, **kwargs):
+        if prompt is not None or negative_prompt is not None or ip_adapter_image is not None or cross_attention_kwargs is not None \
+                or clip_skip is not None or timesteps is not None:
+            raise NotImplementedError("text prompts / IP-adapter / LoRA / clip_skip / custom timesteps are not part of the PCDMs path")
+        if prompt_embeds is None or simg_mask_latents is None or mask is None or cond_pose is None:
+            raise ValueError("simg_mask_latents, mask, cond_pose and prompt_embeds are required")
+        device = self.device
+        N = num_images_per_prompt
+        h, w = simg_mask_latents.shape[-2:]
+        height, width = height or h * self.vae_scale_factor, width or w * self.vae_scale_factor
+        if (height // self.vae_scale_factor, width // self.vae_scale_factor) != (h, w):
+            raise ValueError("height / width do not match simg_mask_latents")
+        f32 = dict(device=device, dtype=torch.float32)
+        do_cfg = guidance_scale > 1.0
+        bs = prompt_embeds.shape[0]
+        pe = prompt_embeds.to(**f32).repeat_interleave(N, 0)                    # encode_prompt: repeat per prompt (:404-406)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("negative_prompt_embeds is required with guidance_scale > 1 (the notebook passes image_proj_model(zeros))")
+            feature_f = torch.cat([negative_prompt_embeds.to(**f32).repeat_interleave(N, 0), pe])
+        else:
+            feature_f = pe
+        rep = 2 if do_cfg else 1
+
+        def per_sample(x):   # [1 | bs*N, ...] as given -> broadcastable by the kernels (1) or the full CFG-doubled batch
+            x = x.to(**f32)
+            return x.contiguous() if x.shape[0] == 1 else torch.cat([x] * rep).contiguous()
+        mask_t, masked, pose_cond = per_sample(mask), per_sample(simg_mask_latents), per_sample(cond_pose)
+        for name, t in (("mask", mask_t), ("simg_mask_latents", masked), ("cond_pose", pose_cond)):
+            if t.shape[0] not in (1, rep * bs * N):
+                raise ValueError(f"{name}: batch {t.shape[0] // (rep if t.shape[0] != 1 else 1)} does not match {bs * N} samples")
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        ts = self.scheduler.timesteps
+        lat = self.prepare_latents(bs * N, 4, height, width, torch.float32, device, generator, latents).contiguous()
+        extra = self.prepare_extra_step_kwargs(generator, eta)
+        cb = None
+        if callback_on_step_end is not None:   # diffusers >= 0.22 callback protocol (:1150-1158), latents only
+            def cb(i, t, cur):
+                callback_on_step_end(self, i, t, {"latents": cur})
+        lat = self._sample(lat, mask_t, masked, pose_cond, feature_f.contiguous(), None, ts, do_cfg, guidance_scale, guidance_rescale, eta,
+                           extra, mode, use_graph, cb, 1)
         images = self._postprocess(lat, output_type)
         if not return_dict:
             return (images, None)

@@ -111,6 +111,39 @@ def test_simple_pipeline_and_guidance_rescale(gpu_backend):
     assert torch.allclose(a, b, atol=1e-4, rtol=1e-4)
 
 
+def test_pcdms_notebook_pipeline(backend):
+    """The notebook's caller (src/pipelines/PCDMs_pipeline.py:893-1184): tensors in, NON-zero unconditional context
+    (image_proj_model(zeros)), no class_labels, un-doubled pose -- vs the oracle loop with the same conditioning."""
+    from pcdms_amd import PCDMsPipeline, UNet2DConditionModel
+    cfg = UNetConfig.tiny(class_embed_type=None, projection_class_embeddings_input_dim=None)
+    sd = synth_state_dict(cfg, seed=6, random_affine=True)
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(backend.device)
+    N, h, w, L, steps = (1, 8, 8, 4, 2) if backend.is_emu else (2, 16, 24, 9, 6)
+    inp = synth_inputs(cfg, h, w, N, L_img=L)
+    g = torch.Generator().manual_seed(3)
+    neg = torch.randn(1, L, cfg.cross_attention_dim, generator=g) * 0.5
+    ref = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps,
+                        use_prior_embed=False, uncond_feature=neg, **inp)
+    dev = backend.device
+    pipe = PCDMsPipeline(m, DDIMScheduler.from_config(SD21))
+    mask = torch.cat([torch.ones(1, 1, h, w // 2), torch.zeros(1, 1, h, w // 2)], dim=3)
+    seen = []
+    out = pipe(simg_mask_latents=inp["masked_latents"].to(dev), mask=mask.to(dev), cond_pose=inp["st_pose_f"].to(dev),
+               prompt_embeds=inp["s_img_proj_f"].to(dev), negative_prompt_embeds=neg.to(dev), num_images_per_prompt=N, guidance_scale=2.0,
+               num_inference_steps=steps, latents=inp["latents"].to(dev), output_type="latent",
+               callback_on_step_end=None if backend.is_emu else (lambda p, i, t, kw: seen.append(i) or {}))
+    backend.sync()
+    assert _rel(out.latents, ref) <= 3e-2, _rel(out.latents, ref)
+    assert backend.is_emu or seen == list(range(steps))
+    with pytest.raises(NotImplementedError):
+        pipe(simg_mask_latents=inp["masked_latents"], mask=mask, cond_pose=inp["st_pose_f"], prompt="a photo", prompt_embeds=neg)
+    with pytest.raises(ValueError):
+        pipe(simg_mask_latents=inp["masked_latents"].to(dev), mask=mask.to(dev), cond_pose=inp["st_pose_f"].to(dev),
+             prompt_embeds=inp["s_img_proj_f"].to(dev), guidance_scale=2.0)
+
+
 @pytest.mark.gpu
 def test_stage3_refine_pipeline(gpu_backend):
     """§8f N2: stock UNet (in_channels 8, no class embedding / pose) + the stage-3 loop vs the oracle restatement."""
