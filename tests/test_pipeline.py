@@ -40,7 +40,7 @@ def _call(pipe, inp, dev, N, steps, h, w, **kw):
 
 def test_pipeline_ddim_vs_oracle(backend):
     cfg = UNetConfig.tiny()
-    N, h, w, L, steps = (1, 8, 8, 4, 2) if backend.is_emu else (2, 16, 24, 9, 10)
+    N, h, w, L, steps = (1, 8, 8, 4, 1) if backend.is_emu else (2, 16, 24, 9, 10)   # (emulator: ~20 s per UNet forward)
     sd, m = _build(backend, cfg)
     inp = synth_inputs(cfg, h, w, N, L_img=L)
     ref = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=N, guidance_scale=2.0,
@@ -64,7 +64,7 @@ def test_pipeline_ddim_vs_oracle(backend):
 def test_pipeline_unipc_and_identities(backend):
     """UniPC (the shipped driver's scheduler) through the reference-semantics loop; g=1 disables CFG."""
     cfg = UNetConfig.tiny()
-    N, h, w, L, steps = (1, 8, 8, 4, 3) if backend.is_emu else (2, 16, 24, 9, 8)
+    N, h, w, L, steps = (1, 8, 8, 4, 2) if backend.is_emu else (2, 16, 24, 9, 8)
     sd, m = _build(backend, cfg, seed=1)
     inp = synth_inputs(cfg, h, w, N, L_img=L)
     ref = stage2_sample(sd, cfg, UniPCOracle(), num_images_per_prompt=N, guidance_scale=2.0,

@@ -97,10 +97,10 @@ def test_unet_tiny(backend):
     dev = backend.device
     s2 = torch.randn(s.shape, generator=torch.Generator().manual_seed(5))
     ehs_d, cl_d, pose_d = e.to(dev), c.to(dev), p.to(dev)
-    o1 = m(s2.to(dev), 500, ehs_d, class_labels=cl_d, my_pose_cond=pose_d).sample.clone()
-    o2 = m(s2.to(dev), 500, ehs_d, class_labels=cl_d, my_pose_cond=pose_d).sample
+    o2 = m(s2.to(dev), 500, ehs_d, class_labels=cl_d, my_pose_cond=pose_d).sample.clone()
     backend.sync()
-    assert torch.equal(o1, o2)
+    if not backend.is_emu:   # run-to-run determinism (skipped under the emulator: ~20 s per forward)
+        assert torch.equal(o2, m(s2.to(dev), 500, ehs_d, class_labels=cl_d, my_pose_cond=pose_d).sample)
     sd = m.state_dict()
     _check(o2, unet_forward(sd, cfg, s2, 500, e, c, p))
 
