@@ -145,6 +145,27 @@ def test_pcdms_notebook_pipeline(backend):
 
 
 @pytest.mark.gpu
+def test_two_pairs_per_call_equals_two_calls(gpu_backend):
+    """Extension beyond the reference (whose ``repeat(bs * N)`` only works for one pair per call): a call
+    with two (source, target) pairs gives, pair by pair, what two single-pair calls give (sample index = pair * N + k)."""
+    cfg = UNetConfig.tiny()
+    sd, m = _build(gpu_backend, cfg, seed=2)
+    dev = gpu_backend.device
+    N, h, w, L, steps = 2, 16, 16, 7, 3
+    a, b = synth_inputs(cfg, h, w, N, L_img=L), synth_inputs(cfg, h, w, N, L_img=L)
+    g = torch.Generator().manual_seed(17)
+    for k in ("masked_latents", "st_pose_f", "s_img_proj_f", "pred_t_img_embed", "latents"):   # a different second pair
+        b[k] = b[k] + 0.3 * torch.randn(b[k].shape, generator=g)
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    one = [_call(pipe, x, dev, N, steps, h, w) for x in (a, b)]
+    both = {k: torch.cat([a[k], b[k]]) for k in a}
+    two = _call(pipe, both, dev, N, steps, h, w)
+    assert two.shape == (2 * N, 4, h, w)
+    r0, r1 = _rel(two[:N], one[0].cpu()), _rel(two[N:], one[1].cpu())
+    assert r0 <= 5e-3 and r1 <= 5e-3, (r0, r1)   # (not bit-equal: the batch size changes the GEMM tiles / split-K the tuner picks)
+
+
+@pytest.mark.gpu
 def test_stage3_refine_pipeline(gpu_backend):
     """§8f N2: stock UNet (in_channels 8, no class embedding / pose) + the stage-3 loop vs the oracle restatement."""
     from oracle.pipeline import stage3_sample
