@@ -6,6 +6,7 @@
 //   mode 2: register-staged (buffer_load_dwordx4 -> VGPRs, later ds_write_b128)
 //   mode 3 / 4: LDS-DMA pieces spread over the four k-steps, issued after / before each k-step's MFMAs
 //   mode 5: LDS-DMA, 3-stage ring, two tiles in flight, counted s_waitcnt
+//   KT = 2: BK = 128 (two 64-deep K-tiles per stage and per barrier)
 // The source (8 MiB, L2 / MALL resident) is read with per-lane constant offsets + an SGPR offset, like the real kernel.
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 -o gemm_loadpath gemm_loadpath.hip
 #include <hip/hip_runtime.h>
@@ -31,11 +32,11 @@ __device__ __forceinline__ void wait_all_then_barrier() { asm volatile("s_waitcn
 template <int N> __device__ __forceinline__ void wait_vm_then_barrier() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int NW, int MODE>
+template <int NW, int MODE, int KT = 1>
 __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32_t src_bytes, float* out, int iters) {
     constexpr int ROWS = NW == 4 ? 256 : 384;   // A rows + B rows of the block tile (128+128 or 256+128)
-    constexpr int PIECES = ROWS / 8 / NW;       // 1 KiB pieces per wave per K-tile (8 rows x 128 B each)
-    constexpr int STAGE = ROWS * 64;            // u16 elements per stage
+    constexpr int PIECES = KT * ROWS / 8 / NW;  // 1 KiB pieces per wave per stage (8 rows x 128 B each; KT K-tiles of 64 per stage)
+    constexpr int STAGE = KT * ROWS * 64;       // u16 elements per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u16* ring = (u16*)smem;                     // [2 or 3][ROWS][64]
     const int lane = threadIdx.x & 63;
@@ -94,10 +95,11 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
         } else if (MODE != 3 && MODE != 4) {
             issue(it + 1, nxt);
         }
-        const u16* as = ring + cur * STAGE + arow * 64;
-        const u16* bs = ring + cur * STAGE + brow * 64;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks4 = 0; ks4 < 4 * KT; ++ks4) {
+            const int ks = ks4 & 3;
+            const u16* as = ring + cur * STAGE + (ks4 >> 2) * ROWS * 64 + arow * 64;
+            const u16* bs = ring + cur * STAGE + (ks4 >> 2) * ROWS * 64 + brow * 64;
             const int co = ((ks * 2 + fhalf) ^ fsw) * 8;
             u16x8 xf[2], wf[2];
 #pragma unroll
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
             for (int i = 0; i < 2; ++i) wf[i] = *(const u16x8*)(bs + i * 32 * 64 + co);
             if (MODE == 4) {
 #pragma unroll
-                for (int j = ks * PIECES / 4; j < (ks + 1) * PIECES / 4; ++j) issue_piece(it + 1, nxt, j);
+                for (int j = ks4 * PIECES / (4 * KT); j < (ks4 + 1) * PIECES / (4 * KT); ++j) issue_piece(it + 1, nxt, j);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma(wf[i], xf[j], acc[i][j]);
             if (MODE == 3) {
 #pragma unroll
-                for (int j = ks * PIECES / 4; j < (ks + 1) * PIECES / 4; ++j) issue_piece(it + 1, nxt, j);
+                for (int j = ks4 * PIECES / (4 * KT); j < (ks4 + 1) * PIECES / (4 * KT); ++j) issue_piece(it + 1, nxt, j);
             }
         }
         if (MODE == 2) {   // the fetched tile goes to the other stage (its readers finished before the barrier above)
@@ -132,25 +134,25 @@ __global__ __launch_bounds__(NW * 64) void k(const u16* __restrict__ src, uint32
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int NW, int MODE>
+template <int NW, int MODE, int KT = 1>
 void run(int blocks_per_cu, const u16* src, uint32_t src_bytes, const char* name) {
     float* out;
     const int blocks = 256 * blocks_per_cu, iters = 2000;
-    constexpr int smem = (MODE == 5 ? 3 : 2) * (NW == 4 ? 256 : 384) * 128;
+    constexpr int smem = (MODE == 5 ? 3 : 2) * KT * (NW == 4 ? 256 : 384) * 128;
     hipMalloc(&out, (size_t)blocks * NW * 64 * 4);
-    hipFuncSetAttribute((const void*)k<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)k<NW, MODE, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    k<NW, MODE><<<blocks, NW * 64, smem>>>(src, src_bytes, out, 10);
+    k<NW, MODE, KT><<<blocks, NW * 64, smem>>>(src, src_bytes, out, 10);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<NW, MODE><<<blocks, NW * 64, smem>>>(src, src_bytes, out, iters);
+    k<NW, MODE, KT><<<blocks, NW * 64, smem>>>(src, src_bytes, out, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)blocks * NW * iters * 16 * 32768.0;
+    const double flops = (double)blocks * NW * iters * 16 * KT * 32768.0;
     printf("%-58s blk/CU %d : %8.1f TF/s  (%.3f ms)\n", name, blocks_per_cu, flops / ms / 1e9, ms);
     hipFree(out);
 }
@@ -169,6 +171,8 @@ int main() {
     run<8, 0>(1, src, bytes, "256x128/8 waves, LDS-resident (ceiling)");
     run<8, 1>(1, src, bytes, "256x128/8 waves, LDS-DMA 6 x 1 KiB per wave per K-tile");
     run<8, 2>(1, src, bytes, "256x128/8 waves, register-staged (6 loads + 6 ds_write_b128)");
+    run<4, 1, 2>(1, src, bytes, "128x128/4 waves, LDS-DMA, BK = 128 (one barrier per 32 MFMAs)");
+    run<4, 3, 2>(1, src, bytes, "128x128/4 waves, LDS-DMA spread, BK = 128");
     run<8, 3>(1, src, bytes, "256x128/8 waves, LDS-DMA spread over k-steps, after MFMAs");
     run<8, 5>(1, src, bytes, "256x128/8 waves, LDS-DMA 3 stages / 2 tiles in flight");
     return 0;
