@@ -10,7 +10,8 @@
  * Conventions: plain pointers to DEVICE memory, sizes as ints, a hipStream_t (passed as void*),
  * every call asynchronous on that stream, no allocation inside, no global state.  Activations
  * are NHWC / token-major bf16 ("u16" storage); statistics, biases and time embeddings fp32.
- * Return 0 on success, a negative code on bad arguments (-1) or launch failure (<= -1000).
+ * Return 0 on success, a negative code otherwise: -1 bad arguments (incl. a tile configuration that is not valid for the
+ * problem), -2 an operand beyond the 2 GiB range of the 32-bit buffer offsets, <= -1000 a HIP launch failure (-1000 - hipError_t).
  */
 #ifndef PCDM_H
 #define PCDM_H
