@@ -16,10 +16,11 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, ops
+from ._module import ModuleSurface
 from .ops import BF16
 
 
-class _HipModule:
+class _HipModule(ModuleSurface):
     """Minimal nn.Module-like surface (to / eval / load_state_dict / state_dict) shared by the two nets."""
 
     _name = "module"
@@ -36,9 +37,6 @@ class _HipModule:
     @property
     def device(self):
         return self._device
-
-    def eval(self):
-        return self
 
     def to(self, *args, **kwargs):
         device = kwargs.get("device")

@@ -25,6 +25,7 @@ from typing import Any, Dict, Iterator, List, Optional, Tuple, Union
 import torch
 
 from . import ops
+from ._module import ModuleSurface
 from .ops import BF16, PackedWeight
 
 _DEFAULT_CONFIG: Dict[str, Any] = dict(
@@ -89,7 +90,7 @@ def _as_tuple(v, n):
     return tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
 
 
-class Stage2_InapintUNet2DConditionModel:
+class Stage2_InapintUNet2DConditionModel(ModuleSurface):
     """Drop-in for the reference class of the same (sic) name; inference only."""
 
     _pose_required = True   # the stage-2 forward adds my_pose_cond unconditionally (ref :742)

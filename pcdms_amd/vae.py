@@ -21,6 +21,7 @@ from typing import Any, Dict, Iterator, Optional, Tuple
 import torch
 
 from . import _lib, ops
+from ._module import ModuleSurface
 from .ops import BF16
 
 SD21_VAE_CONFIG = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
@@ -71,7 +72,7 @@ class DecoderOutput:
         return (self.sample,)[i]
 
 
-class AutoencoderKL:
+class AutoencoderKL(ModuleSurface):
     def __init__(self, **kwargs):
         cfg = dict(SD21_VAE_CONFIG)
         cfg.update({k: v for k, v in kwargs.items() if k in cfg or k.startswith("_")})

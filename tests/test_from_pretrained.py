@@ -133,3 +133,20 @@ def test_scheduler_from_config_of_another_scheduler():
     k = P.UnCLIPScheduler.from_config({"_class_name": "UnCLIPScheduler", "clip_sample": True, "clip_sample_range": 10.0,
                                        "num_train_timesteps": 1000, "prediction_type": "sample", "variance_type": "fixed_small_log"})
     assert k.config.prediction_type == "sample" and k.config.clip_sample_range == 10.0
+
+
+def test_module_surface_the_drivers_touch():
+    """``.eval() / .half() / .float() / .requires_grad_(False) / .parameters() / .modules()`` on every model object (the drivers chain
+    ``.to(device).eval()``, stage2_batchtest_inpaint_model.py:95-99); training is out of scope and says so."""
+    objs = [P.Stage2_InapintUNet2DConditionModel(**{k: v for k, v in SD21_UNET_JSON.items() if k in ("block_out_channels", "attention_head_dim", "cross_attention_dim")}),
+            P.AutoencoderKL(block_out_channels=(64, 64, 128, 128)), P.Stage1_PriorTransformer(num_attention_heads=2, num_layers=1, embedding_dim=1024, num_embeddings=2),
+            P.Dinov2Model(hidden_size=128, num_hidden_layers=1, num_attention_heads=2), P.CLIPVisionModelWithProjection(hidden_size=128, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2),
+            P.ControlNetConditioningEmbedding(64), P.ImageProjModel_p(128, 64, 64)]
+    for m in objs:
+        assert m.eval() is m and m.requires_grad_(False) is m and m.half() is m and m.float() is m and m.train(False) is m
+        assert isinstance(list(m.parameters()), list) and isinstance(list(m.modules()), list)
+        with pytest.raises(NotImplementedError):
+            m.train()
+    iproj = objs[-1]
+    iproj.load_state_dict({k: torch.zeros(s) for k, s in iproj.expected_shapes().items()})
+    assert sum(p.numel() for p in iproj.parameters()) == 128 * 64 + 64 + 2 * 64 + 64 * 64 + 64
