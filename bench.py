@@ -58,6 +58,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
     use_dist = world > 1 or os.environ.get("PCDM_BENCH_FORCE_DIST") == "1"   # (1-rank RCCL group: test hook)
+    if world > 1:   # every rank generates the synthetic weights on the host: share the cores instead of oversubscribing them
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
