@@ -9,7 +9,10 @@ One "step" = one complete sampling call of the hot path: 50 DDIM denoise steps (
 (source, target) pair, inputs resident in HBM, final latents returned (VAE decode is outside the hot
 path).  Workload at N=1 = BASELINE.json configs[1] ("stage2 inpaint, 352x512,
 batch=4, 50 DDIM steps, bf16, 1xMI355X").  N>1: every rank samples its own pair with the same
-per-GPU batch (weak scaling), then ONE RCCL all-gather collects the final latents.
+per-GPU batch (weak scaling), then ONE RCCL all-gather collects the final latents.  Launched bare
+(``python bench.py --gpus 8``, no WORLD_SIZE in the environment) it spawns the N ranks itself through
+``torch.distributed.run`` on 127.0.0.1; under an external launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+At N=8 it also reports BASELINE.json configs[2]'s own per-GPU batch (8 => 64 images per step) as ``config.configs2``.
 
 Synthetic data: seeded random-init weights of the full 868.9 M-parameter stage-2
 UNet and seeded synthetic conditioning -- there are no checkpoints / DeepFashion pairs offline.
@@ -48,17 +51,29 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the separate VAE encode/decode timing (SURVEY.md §8f N1)")
+    ap.add_argument("--no-configs2", action="store_true", help="at --gpus 8: skip the extra batch-8-per-GPU (configs[2]) measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher (one process per GPU, rendezvous on 127.0.0.1); rank 0's
+        # JSON line is the only thing the children print to stdout
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     use_dist = world > 1 or os.environ.get("PCDM_BENCH_FORCE_DIST") == "1"   # (1-rank RCCL group: test hook)
-    if world > 1:   # every rank generates the synthetic weights on the host: share the cores instead of oversubscribing them
+    if world > 1:
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -79,7 +94,10 @@ def main():
     h, w = args.height // 8, 2 * args.width // 8
     N = args.batch
     t0 = time.time()
-    sd = synth_state_dict(cfg, seed=0)
+    # N = 1: the CPU-seeded weights the parity tests and the cpu_baseline leg use.  N > 1: every rank would spend ~15 s x N of shared
+    # host cores on 869 M host random numbers; the ranks draw the same distribution on their GPU instead (same seeds => the same
+    # replicated weights on every rank)
+    sd = synth_state_dict(cfg, seed=0) if world == 1 else device_state_dict(cfg, 0, dev)
     unet = Stage2_InapintUNet2DConditionModel(
         in_channels=9, block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.attention_head_dim,
         cross_attention_dim=1024, use_linear_projection=True, class_embed_type="projection",
@@ -96,41 +114,44 @@ def main():
     dinp = {k: v.to(dev) for k, v in inp.items()}
     setup_s = time.time() - t0
 
-    def one_call(latents):
-        return pipe(height=args.height, width=2 * args.width, masked_latents=dinp["masked_latents"],
-                    s_img_proj_f=dinp["s_img_proj_f"], st_pose_f=dinp["st_pose_f"],
-                    pred_t_img_embed=dinp["pred_t_img_embed"], latents=latents, num_images_per_prompt=N,
-                    guidance_scale=2.0, num_inference_steps=args.ddim_steps, output_type="latent",
-                    use_graph=not args.no_graph).latents
+    def timed(dinp, n_img, steps, warmup):
+        """W warm-up + K timed sampling calls of n_img images per GPU, barrier + synchronize on both sides, max over ranks."""
+        gathered = torch.empty(world * n_img, 4, h, w, dtype=torch.float32, device=dev) if use_dist else None
 
-    gathered = torch.empty(world * N, 4, h, w, dtype=torch.float32, device=dev) if use_dist else None
+        def step():
+            lat = pipe(height=args.height, width=2 * args.width, masked_latents=dinp["masked_latents"],
+                       s_img_proj_f=dinp["s_img_proj_f"], st_pose_f=dinp["st_pose_f"],
+                       pred_t_img_embed=dinp["pred_t_img_embed"], latents=dinp["latents"], num_images_per_prompt=n_img,
+                       guidance_scale=2.0, num_inference_steps=args.ddim_steps, output_type="latent",
+                       use_graph=not args.no_graph).latents
+            if use_dist:
+                dist.all_gather_into_tensor(gathered, lat)   # the single collective of the path (RCCL over xGMI)
+            return lat
 
-    def step():
-        lat = one_call(dinp["latents"])
+        for _ in range(warmup):
+            step()
         if use_dist:
-            dist.all_gather_into_tensor(gathered, lat)   # the single collective of the path (RCCL over xGMI)
-        return lat
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        assert torch.isfinite(out).all()
+        return elapsed
 
-    for _ in range(args.warmup):
-        step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out).all()
+    elapsed = timed(dinp, N, args.steps, args.warmup)
     images = world * N * args.steps
     value = images / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    e2e_tflops = value * FLOP_PER_IMAGE * (h * w) / (64 * 88) / world / 1e12
 
     result = {
         "metric": "images/sec (50-step DDIM, 352x512 stage2)", "value": round(value, 4), "unit": "images/s",
@@ -141,13 +162,29 @@ def main():
                                "868.9M-param UNet, 258 context tokens, bf16 MFMA / fp32 accumulate",
                    "global_batch": world * N, "ms_per_denoise_step": round(ms_per_step / args.ddim_steps, 3),
                    "parallelism": f"dp{world}", "hipgraph": not args.no_graph, "setup_s": round(setup_s, 1),
-                   "e2e_tflops_per_gpu": round(value * FLOP_PER_IMAGE * (h * w) / (64 * 88) / world / 1e12, 1)},
+                   "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                   "e2e_tflops_per_gpu": round(e2e_tflops, 1),
+                   "flops_note": "e2e_tflops_per_gpu and roofline.e2e_frac credit the UN-HOISTED algorithmic FLOPs of SURVEY.md §8d "
+                                 "(118.84 TFLOP per image); executed FLOPs are ~3.5% lower: the cross-attention K/V projections run once "
+                                 "per call instead of once per step, and the all-zero-context CFG half of every cross-attention "
+                                 "(LN2, to_q, QK^T/PV, to_out contraction) is skipped (output == to_out.bias exactly)"},
     }
+    if world == 8 and N != 8 and not args.no_configs2:
+        # BASELINE.json configs[2] as written: batch 64 over 8 GPUs = 8 images (UNet batch 16) per GPU; same protocol
+        inp8 = synth_inputs(cfg, h, w, 8)
+        inp8["latents"] = torch.randn(inp8["latents"].shape, generator=torch.Generator().manual_seed(2000 + rank))
+        el8 = timed({k: v.to(dev) for k, v in inp8.items()}, 8, args.steps, max(1, args.warmup))
+        result["config"]["configs2"] = {"workload": "stage2 inpaint, 352x512, batch=64 (8 per GPU, UNet batch 16), 50 DDIM steps, dp8",
+                                        "value": round(world * 8 * args.steps / el8, 4), "unit": "images/s",
+                                        "ms_per_step": round(el8 / args.steps * 1e3, 3)}
+        timed(dinp, N, 1, 0)   # every rank: back to the headline workload's captured state (kernel_roofline re-runs single steps of it)
 
     if rank == 0 and not args.no_vae:
         result["config"].update(vae_timing(dev, N, args.height, 2 * args.width, ms_per_step))
     if rank == 0 and not args.no_roofline:
         result["roofline"] = kernel_roofline(pipe, ops, dinp, N, h, w)
+        # whole-path fraction of the MFMA roof beside the dominant family's (un-hoisted algorithmic FLOPs, see config.flops_note)
+        result["roofline"]["e2e_frac"] = round(e2e_tflops / PEAK_BF16_TFLOPS, 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(sd, cfg, inp, N, args.ddim_steps)
     if use_dist:
@@ -155,6 +192,29 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def device_state_dict(cfg, seed, dev):
+    """The distribution of oracle.unet.synth_state_dict drawn with per-tensor seeded DEVICE generators: identical
+    on every rank of one job (same seeds, same GPU type), no host RNG time.  Multi-GPU bench only -- parity tests and the CPU
+    baseline use the CPU-seeded weights."""
+    import math
+    import zlib
+
+    from oracle import unet as OU
+    shapes = dict(OU.param_shapes(cfg))
+    sd = {}
+    for key, shape in shapes.items():
+        wshape = shapes[key[: key.rfind(".") + 1] + "weight"]
+        if len(wshape) == 1:
+            sd[key] = torch.ones(shape) if key.endswith("weight") else torch.zeros(shape)
+            continue
+        g = torch.Generator(device=dev).manual_seed((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+        t = (torch.rand(shape, generator=g, device=dev) * 2 - 1) / math.sqrt(math.prod(wshape[1:]))
+        if key.endswith("weight") and any(key.endswith(sfx) for sfx in OU._HALF_SCALED):
+            t = t * 0.5
+        sd[key] = t
+    return sd
 
 
 def vae_timing(dev, N, height, width, ms_per_call):
@@ -254,11 +314,13 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
 
 
 def cpu_baseline(sd, cfg, inp, N, ddim_steps):
-    """The fp32 PyTorch CPU restatement (oracle/) timed on this box's host cores on a bounded sample:
-    1 warm-up + 2 timed denoise steps (UNet batch 2N at the full latent size + CFG + DDIM update),
-    extrapolated to the 50-step call.  Substitute for the reference's CPU diffusers path, which cannot run
-    (diffusers is not installed / vendored)."""
-    from oracle.pipeline import build_conditioning
+    """The fp32 PyTorch CPU restatement (oracle/) timed on this box's host cores.  Substitute for the reference's CPU diffusers
+    path, which cannot run (diffusers is not installed / vendored).  Two records:
+      * ``value``: configs[1] on a bounded sample -- 1 warm-up + 1 timed denoise step (UNet batch 2N at the full latent size +
+        CFG + DDIM update), extrapolated to the 50-step call;
+      * ``config1``: BASELINE.json configs[0] in FULL -- one 256x256 pair (canvas 512x256, latent 32x64), N = 1, 20 DDIM steps,
+        guidance 2.0, fp32: wall seconds of the whole sampling loop (SURVEY.md §8d "config 1")."""
+    from oracle.pipeline import build_conditioning, stage2_sample, synth_inputs
     from oracle.schedulers import DDIMOracle
     from oracle.unet import unet_forward
     cores = torch.get_num_threads()
@@ -268,7 +330,7 @@ def cpu_baseline(sd, cfg, inp, N, ddim_steps):
     lat = inp["latents"].clone()
     times = []
     with torch.no_grad():
-        for i, t in enumerate(sch.timesteps[:3]):
+        for i, t in enumerate(sch.timesteps[:2]):
             t0 = time.perf_counter()
             x = torch.cat([lat] * 2)
             eps = unet_forward(sd, cfg, torch.cat([x, c["mask"], c["masked_latents"]], 1), t, c["feature_f"],
@@ -276,10 +338,17 @@ def cpu_baseline(sd, cfg, inp, N, ddim_steps):
             u, cn = eps.chunk(2)
             lat = sch.step(u + 2.0 * (cn - u), t, lat)
             times.append(time.perf_counter() - t0)
-    per_step = sum(times[1:]) / len(times[1:])
+        per_step = times[-1]
+        inp1 = synth_inputs(cfg, 32, 64, 1)
+        t0 = time.perf_counter()
+        out1 = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=1, guidance_scale=2.0, num_inference_steps=20, **inp1)
+        c1_s = time.perf_counter() - t0
+    assert torch.isfinite(out1).all()
     return {"value": round(N / (per_step * ddim_steps), 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"2 timed denoise steps (after 1 warm-up) of the same workload (UNet batch {2 * N}, fp32, "
-                      f"torch {torch.__version__} CPU ops), {per_step:.2f} s/step, extrapolated x{ddim_steps}"}
+            "sample": f"1 timed denoise step (after 1 warm-up) of the same workload (UNet batch {2 * N}, fp32, "
+                      f"torch {torch.__version__} CPU ops), {per_step:.2f} s/step, extrapolated x{ddim_steps}",
+            "config1": {"workload": "configs[0]: 1 pair 256x256 (latent 32x64), N=1, 20 DDIM steps, guidance 2.0, fp32 CPU, full run",
+                        "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}
 
 
 if __name__ == "__main__":

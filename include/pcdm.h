@@ -87,6 +87,9 @@ typedef struct pcdm_gemm_params {
     int32_t act;       /* PCDM_ACT_*: out = act(acc + bias + rowvec) + residual.  With PCDM_EPI_GEGLU: gate activation, 0 = GELU(erf) (GEGLU),
                           PCDM_ACT_SILU = SwiGLU (DINOv2 SwiGLUFFN).  SiLU: the convs of
                           ControlNetConditioningEmbedding (stage2_batchtest_inpaint_model.py:101); GELU(erf): ImageProjModel_p (:54-56) */
+    int32_t zero_rows; /* linear only: the caller guarantees A rows [0, zero_rows) are all-zero; they are not read and tiles entirely
+                          inside them run the epilogue only.  The CFG unconditional half of attn2.to_out: context == 0 => attention
+                          output == 0 => out = bias + residual (stage2_inpaint_pipeline.py:457-458) */
 } pcdm_gemm_params;
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 

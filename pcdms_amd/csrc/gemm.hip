@@ -54,6 +54,7 @@ struct GemmArgs {
     int split_k;   // > 1: K range split over split_k workgroups per tile, fp32 partials to ws, reduced by splitk_reduce_kernel
     float* ws;
     int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
+    int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
     int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs
 };
 
@@ -155,8 +156,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                 if (iy >= 0 && iy < Hv_ && ix >= 0 && ix < Wv_) a_mask[j] |= 1 << tp;
             }
         } else {
-            a_off[j] = (uint32_t)((int64_t)m * p.lda * 2) + ck;
-            a_off2[j] = (uint32_t)((int64_t)m * p.lda2 * 2) + ck;
+            // rows the caller declared all-zero are "out of range": the bounds check delivers zeros, nothing is fetched
+            a_off[j] = m < p.zero_rows ? kOOB : (uint32_t)((int64_t)m * p.lda * 2) + ck;
+            a_off2[j] = m < p.zero_rows ? kOOB : (uint32_t)((int64_t)m * p.lda2 * 2) + ck;
         }
     }
     uint32_t b_off[BI];
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 
     const int nkt_all = p.K / BK;
     kt0 = (int)((int64_t)ksplit * nkt_all / p.split_k);
-    const int nkt = (int)((int64_t)(ksplit + 1) * nkt_all / p.split_k) - kt0;  // this workgroup's K-tiles
+    int nkt = (int)((int64_t)(ksplit + 1) * nkt_all / p.split_k) - kt0;  // this workgroup's K-tiles
+    if (!CONV && m0 + BM <= p.zero_rows) nkt = 0;   // the whole A tile is declared zero: epilogue only (bias + residual)
     const int frow = lane & 31, fsw = (lane >> 1) & 7, fhalf = lane >> 5;  // (row>>1)&7 == (lane>>1)&7: tile rows are 32-aligned
     if constexpr (STAG) {
         static_assert(NW == 8 && D == 2, "staggered schedule: 8 waves, 3 stages");
@@ -619,6 +622,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.tiles_m = a.tiles_n = 0;
     a.debug = p->tile >> 8;
     a.act = p->act;
+    a.zero_rows = p->zero_rows;
+    if (a.zero_rows < 0 || a.zero_rows > p->M || (a.zero_rows && p->conv)) return -1;
     if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act == PCDM_ACT_GELU && p->epilogue == PCDM_EPI_GEGLU)) return -1;
     a.split_k = p->split_k > 1 ? p->split_k : 1;
     a.ws = p->ws;

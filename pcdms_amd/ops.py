@@ -155,7 +155,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
-         use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE) -> torch.Tensor:
+         use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0) -> torch.Tensor:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``."""
     p = GemmParams()
@@ -195,6 +195,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.res_mod = res_mod
     p.epilogue = epilogue
     p.act = act
+    p.zero_rows = zero_rows   # (linear) A rows < zero_rows are declared all-zero: never read
     p.vt_col0 = vt_col0
     p.out = _ptr(out)
     p.ldo = out.stride(0) if (out.dim() == 2 and epilogue != EPI_NCHW_F32) else pw.N
@@ -205,7 +206,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     split = 1
     if tile == 0 and AUTOTUNE and a.is_cuda:
         key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
-               a2 is not None, residual is not None)   # (w_ld does not change the best tile)
+               a2 is not None, residual is not None) + ((True,) if zero_rows else ())   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
         if tile == 0 and not torch.cuda.is_current_stream_capturing():
             tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device, out)
@@ -220,6 +221,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         e0.record()
         _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
         e1.record()
+        # algorithmic FLOPs stay the un-hoisted 2*M*N*K also when zero_rows skips part of the contraction
         LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split)))
         return out
     _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
@@ -234,13 +236,26 @@ _TUNED: dict = {}
 _WS: dict = {}
 
 
+_WS_RETIRED: list = []   # outgrown workspaces are kept: a captured hipGraph may still hold their address
+_WS_GEN: dict = {}
+
+
+def workspace_generation(device) -> int:
+    """Changes whenever the split-K workspace of ``device`` is re-allocated (a graph captured before that must be re-captured
+    to use the new one; the old one stays allocated, so replaying a stale graph is slow-path-correct, never a use-after-free)."""
+    return _WS_GEN.get(torch.device(device), 0)
+
+
 def _splitk_ws(device, floats: int) -> torch.Tensor:
-    """fp32 split-K workspace (one per device; only grows outside graph capture)."""
+    """fp32 split-K workspace (one per device; only grows outside graph capture; never freed)."""
     ws = _WS.get(device)
     if ws is None or ws.numel() < floats:
         if ws is not None and device.type == "cuda" and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("split-K workspace would grow during graph capture")
+        if ws is not None:
+            _WS_RETIRED.append(ws)
         ws = _WS[device] = torch.empty(max(floats, 1 << 24), dtype=torch.float32, device=device)
+        _WS_GEN[device] = _WS_GEN.get(device, 0) + 1
     return ws
 
 

@@ -11,8 +11,10 @@ Nothing in here computes with PyTorch: the forward is a schedule of calls into l
 (hand-written gfx950 HIP, include/pcdm.h) on the current stream.  Activations are NHWC bf16; all
 scratch buffers are preallocated per input shape (static addresses => the whole step can be captured
 in a hipGraph by the pipeline).  Step-invariant work (class embedding, pose layout change,
-cross-attention K/V of the context) is cached on the identity of the
-input tensors.
+cross-attention K/V of the context) is computed by ``prepare_conditioning`` into a
+``Conditioning`` object: the pipelines build one per sampling call and hand it to every step; bare
+``unet(...)`` callers get it through a cache that holds REFERENCES to the three source tensors (so their
+addresses cannot be recycled while the entry lives) and compares tensor identity + in-place version.
 """
 from __future__ import annotations
 
@@ -90,6 +92,19 @@ def _as_tuple(v, n):
     return tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
 
 
+class Conditioning:
+    """Step-invariant part of one sampling call (``prepare_conditioning``): views of the model's scratch buffers."""
+
+    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv")
+
+    def __init__(self, gen: int, B: int, h: int, w: int, L: int):
+        self.gen, self.B, self.h, self.w, self.L = gen, B, h, w, L
+        self.n0 = 0                      # leading batch entries with an all-zero context (cross-attention skipped there)
+        self.cls_emb: Optional[torch.Tensor] = None
+        self.pose_nhwc: Optional[torch.Tensor] = None
+        self.kv: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
 class Stage2_InapintUNet2DConditionModel(ModuleSurface):
     """Drop-in for the reference class of the same (sic) name; inference only."""
 
@@ -134,7 +149,8 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         self._sd: Optional[Dict[str, torch.Tensor]] = None   # fp32 CPU master copy (diffusers key names)
         self._w: Optional[Dict[str, Any]] = None             # packed device weights
         self._bufs: Dict[Tuple, torch.Tensor] = {}
-        self._cache: Dict[str, Tuple[Tuple, Any]] = {}
+        self._cache: Dict[str, Any] = {}
+        self._cond_gen = 0   # bumped by every prepare_conditioning (the shared K/V, pose and class-embedding buffers are rewritten)
 
     # ------------------------------------------------------------------ nn.Module-like surface
     @property
@@ -338,17 +354,82 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             self._bufs[key] = t
         return t
 
-    def _cached(self, slot: str, src: torch.Tensor, extra=()):
-        key = (src.data_ptr(), src._version, tuple(src.shape), src.dtype, *extra)
-        hit = self._cache.get(slot)
-        return hit[1] if hit is not None and hit[0] == key else None
-
-    def _store(self, slot: str, src: torch.Tensor, value, extra=()):
-        self._cache[slot] = ((src.data_ptr(), src._version, tuple(src.shape), src.dtype, *extra), value)
-        return value
-
     def invalidate_caches(self):
+        """Drop the bare-``forward`` conditioning cache (and the references it holds to the caller's tensors)."""
         self._cache.clear()
+
+    # ------------------------------------------------------------------ step-invariant conditioning
+    def prepare_conditioning(self, B: int, h: int, w: int, encoder_hidden_states: torch.Tensor,
+                             class_labels: Optional[torch.Tensor], my_pose_cond: Optional[torch.Tensor],
+                             zero_ctx_batches: Optional[int] = None) -> "Conditioning":
+        """Everything of one forward that does not depend on the timestep or the latents:
+        class embedding (ref :688-708), NHWC pose feature (ref :742) and the cross-attention K / V^T of the context for all
+        16 transformer blocks.  Results live in shape-keyed scratch buffers (static addresses: a captured hipGraph stays valid
+        across calls) that every later ``prepare_conditioning`` of the same shape OVERWRITES -- the returned object is valid
+        until then, which ``_forward_nhwc`` checks through the generation counter.
+
+        ``zero_ctx_batches`` = n0: the first n0 batch entries of ``encoder_hidden_states`` are all-zero (the CFG
+        unconditional half, ref stage2_inpaint_pipeline.py:457-458).  ``to_k`` / ``to_v`` have no bias, so K = V = 0 there and
+        the attention output is exactly 0, i.e. ``attn2(x) == to_out.0.bias``: those rows skip
+        LayerNorm-2, ``to_q``, the attention and the ``to_out`` contraction.  ``None`` = find out (one device reduction + sync)."""
+        if self._w is None:
+            self._pack()
+        W, cfg, dev = self._w, self.config, self._device
+        boc = self._boc
+        temb_dim = boc[0] * 4
+        ehs = encoder_hidden_states
+        if ehs.dim() != 3 or ehs.shape[0] != B or ehs.shape[2] != cfg.cross_attention_dim:
+            raise ValueError(f"encoder_hidden_states must be [{B},L,{cfg.cross_attention_dim}], got {tuple(ehs.shape)}")
+        L = ehs.shape[1]
+        self._cond_gen += 1
+        cond = Conditioning(gen=self._cond_gen, B=B, h=h, w=w, L=L)
+        if cfg.class_embed_type == "projection":
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            cl = class_labels.reshape(B, -1).to(dev, torch.float32).contiguous()
+            c1 = ops.small_linear(cl, W["class1"][0], W["class1"][1], self._buf("cls1", (B, temb_dim), torch.float32),
+                                  act_out=True)
+            cond.cls_emb = ops.small_linear(c1, W["class2"][0], W["class2"][1], self._buf("cls2", (B, temb_dim), torch.float32))
+        if my_pose_cond is not None:
+            pose = my_pose_cond
+            if pose.dim() != 4 or pose.shape[0] not in (1, B) or tuple(pose.shape[1:]) != (boc[0], h, w):
+                raise ValueError(f"my_pose_cond must be [1|{B},{boc[0]},{h},{w}], got {tuple(pose.shape)}")
+            cond.pose_nhwc = ops.nchw_to_nhwc_bf16(pose.to(dev), self._buf("pose", (pose.shape[0], h, w, boc[0])))
+        e32 = ehs.to(dev, torch.float32).contiguous()
+        if zero_ctx_batches is None:   # leading all-zero batch entries (bare callers; the pipelines know and say so)
+            nz = (e32.reshape(B, -1) != 0).any(dim=1).to(torch.int32)
+            zero_ctx_batches = int(torch.cumsum(nz, 0).eq(0).sum().item())
+        n0 = int(zero_ctx_batches)
+        if not 0 <= n0 <= B:
+            raise ValueError("zero_ctx_batches out of range")
+        if n0 == B:
+            n0 = B - 1 if B > 1 else 0   # keep the kernels' shapes non-empty (the last entry is then computed in full)
+        cond.n0 = n0
+        Bc = B - n0
+        ctx = ops.f32_to_bf16(e32[n0:].reshape(Bc * L, -1), self._buf("ctx", (Bc * L, cfg.cross_attention_dim)))
+        Lp = (L + 7) // 8 * 8
+        for p, c, _ in _transformers(self):
+            kbuf = self._buf(("k2", p), (Bc * L, c))
+            vtbuf = self._buf(("vt2", p), (Bc, c, Lp), zero=True)
+            ops.gemm(ctx, W[p]["kv2"], kbuf, rows_per_batch=L, epilogue=ops.EPI_SPLIT_VT, out2=vtbuf, vt_col0=c)
+            cond.kv[p] = (kbuf, vtbuf)
+        return cond
+
+    def _conditioning_for(self, B, h, w, ehs, class_labels, pose) -> "Conditioning":
+        """Bare ``forward`` callers (the reference pipeline's own loop): reuse the last conditioning
+        iff the caller passed the SAME tensor objects, unmodified (torch's in-place version counter), and nobody has
+        overwritten the buffers since.  The entry keeps the three tensors alive, so a fresh tensor can never sit at a
+        cached tensor's address (the round-1 bug: keys were (data_ptr, _version) of tensors that had been freed)."""
+        srcs = (ehs, class_labels, pose)
+        hit = self._cache.get("cond")
+        if hit is not None:
+            hsrcs, vers, shape, cond = hit
+            if shape == (B, h, w) and cond.gen == self._cond_gen and all(a is b for a, b in zip(srcs, hsrcs)) and \
+                    vers == tuple(None if t is None else t._version for t in srcs):
+                return cond
+        cond = self.prepare_conditioning(B, h, w, ehs, class_labels, pose)
+        self._cache["cond"] = (srcs, tuple(None if t is None else t._version for t in srcs), (B, h, w), cond)
+        return cond
 
     # ------------------------------------------------------------------ forward
     def __call__(self, *args, **kwargs):
@@ -363,7 +444,8 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
                 mid_block_additional_residual: Optional[torch.Tensor] = None,
                 encoder_attention_mask: Optional[torch.Tensor] = None, my_pose_cond: Optional[torch.Tensor] = None,
-                return_dict: bool = True, _step_dev: Optional[torch.Tensor] = None):
+                return_dict: bool = True, _step_dev: Optional[torch.Tensor] = None,
+                _cond: Optional["Conditioning"] = None):
         for name, v in (("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
                         ("added_cond_kwargs", added_cond_kwargs),
                         ("down_block_additional_residuals", down_block_additional_residuals),
@@ -388,18 +470,26 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             raise RuntimeError(f"sample on {sample.device}, model on {self._device}")
         x_in = ops.nchw_to_nhwc_bf16(sample, self._buf("x_in", (B, h, w, self._w["conv_in"].cin)),
                                      cpad=self._w["conv_in"].cin)
-        eps = self._forward_nhwc(x_in, B, h, w, timestep, encoder_hidden_states, class_labels, my_pose_cond, _step_dev)
-        out = eps if sample.dtype == torch.float32 else eps.to(sample.dtype)
+        cond = _cond if _cond is not None else self._conditioning_for(B, h, w, encoder_hidden_states, class_labels, my_pose_cond)
+        eps = self._forward_nhwc(x_in, B, h, w, timestep, cond, _step_dev)
+        # a fresh tensor at the public boundary (nn.Module semantics: two calls never alias); the fused pipeline path uses
+        # _forward_nhwc directly and reads the reused buffer in place
+        out = eps.clone() if sample.dtype == torch.float32 else eps.to(sample.dtype)
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)
 
     # -- the schedule proper; x_in is NHWC bf16 [B,h,w,cin_pad]; returns fp32 NCHW eps (a reused buffer)
-    def _forward_nhwc(self, x_in, B, h, w, timestep, ehs, class_labels, pose, step_dev=None) -> torch.Tensor:
+    def _forward_nhwc(self, x_in, B, h, w, timestep, cond: Conditioning, step_dev=None) -> torch.Tensor:
         W, cfg, dev = self._w, self.config, self._device
         boc, G, eps = self._boc, cfg.norm_num_groups, cfg.norm_eps
         nlev = len(boc)
         temb_dim = boc[0] * 4
+        if cond.gen != self._cond_gen or (cond.B, cond.h, cond.w) != (B, h, w):
+            raise RuntimeError("stale Conditioning: prepare_conditioning() was called again (the shared K/V / pose / class-embedding "
+                               "buffers were overwritten) or the batch / latent size changed")
+        if (cfg.class_embed_type == "projection") != (cond.cls_emb is not None) or (cond.pose_nhwc is None and self._pose_required):
+            raise ValueError("class_labels / my_pose_cond missing from the conditioning")
 
         # ---- 1. time / class embedding (ref :661-708)
         if torch.is_tensor(timestep):
@@ -410,45 +500,13 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             t_dev = torch.tensor([int(timestep)], dtype=torch.int64, device=dev)
         t_emb = ops.timestep_embedding(t_dev, step_dev, self._buf("t_emb", (B, boc[0]), torch.float32),
                                        cfg.flip_sin_to_cos, float(cfg.freq_shift))
-        cls_emb = None
-        if cfg.class_embed_type == "projection":
-            cls_emb = self._cached("cls", class_labels)
-            if cls_emb is None:
-                cl = class_labels.reshape(B, -1).to(dev, torch.float32).contiguous()
-                c1 = ops.small_linear(cl, W["class1"][0], W["class1"][1], self._buf("cls1", (B, temb_dim), torch.float32),
-                                      act_out=True)
-                cls_emb = ops.small_linear(c1, W["class2"][0], W["class2"][1],
-                                           self._buf("cls2", (B, temb_dim), torch.float32))
-                self._store("cls", class_labels, cls_emb)
+        cls_emb, pose_nhwc, kv, L, nzero = cond.cls_emb, cond.pose_nhwc, cond.kv, cond.L, cond.n0
         e1 = ops.small_linear(t_emb, W["time1"][0], W["time1"][1], self._buf("e1", (B, temb_dim), torch.float32), act_out=True)
         # emb = time_emb + class_emb is only ever consumed as silu(emb) (ResnetBlock2D): apply it here, once
         emb_act = ops.small_linear(e1, W["time2"][0], W["time2"][1], self._buf("emb", (B, temb_dim), torch.float32),
                                    add=cls_emb, act_out=2 if cls_emb is not None else 1)
         # every ResnetBlock2D.time_emb_proj(silu(emb)) in one launch
         temb = ops.small_linear(emb_act, W["temb_w"], W["temb_b"], self._buf("temb", (B, W["temb_n"]), torch.float32))
-
-        # ---- step-invariant conditioning (Appendix C-5), cached on tensor identity
-        pose_nhwc = self._cached("pose", pose) if pose is not None else None
-        if pose is not None and pose_nhwc is None:
-            if pose.shape[0] not in (1, B) or tuple(pose.shape[1:]) != (boc[0], h, w):
-                raise ValueError(f"my_pose_cond must be [1|{B},{boc[0]},{h},{w}], got {tuple(pose.shape)}")
-            pose_nhwc = self._store("pose", pose, ops.nchw_to_nhwc_bf16(
-                pose.to(dev), self._buf("pose", (pose.shape[0], h, w, boc[0]))))
-        kv = self._cached("kv", ehs)
-        L = ehs.shape[1]
-        if kv is None:
-            if ehs.shape[0] != B or ehs.shape[2] != cfg.cross_attention_dim:
-                raise ValueError(f"encoder_hidden_states must be [{B},L,{cfg.cross_attention_dim}]")
-            ctx = ops.f32_to_bf16(ehs.reshape(B * L, -1).to(dev, torch.float32).contiguous(),
-                                  self._buf("ctx", (B * L, cfg.cross_attention_dim)))
-            Lp = (L + 7) // 8 * 8
-            kv = {}
-            for p, c, _ in _transformers(self):
-                kbuf = self._buf(("k2", p), (B * L, c))
-                vtbuf = self._buf(("vt2", p), (B, c, Lp), zero=True)
-                ops.gemm(ctx, W[p]["kv2"], kbuf, rows_per_batch=L, epilogue=ops.EPI_SPLIT_VT, out2=vtbuf, vt_col0=c)
-                kv[p] = (kbuf, vtbuf)
-            self._store("kv", ehs, kv)
 
         def resnet(p, x1, x2, HW_, hh, ww, name):
             r = W[p]
@@ -478,12 +536,16 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             ops.gemm(l1, a["qkv"], qk, rows_per_batch=HW_, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * c)
             at = ops.flash_attn(qk[:, :c], qk[:, c:], vt, self._buf("at", (M, c)), B, H, HW_, HW_)
             t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M)
-            # cross-attention over the 258 context tokens
-            l2 = ops.layernorm(t1, a["ln2"][0], a["ln2"][1], 1e-5, self._buf("ln", (M, c)))
-            q2 = ops.gemm(l2, a["q2"], self._buf("q2", (M, c)))
+            # cross-attention over the context tokens; the first n0 batch entries have an all-zero context, for which
+            # attn2(x) == to_out.0.bias exactly: their rows skip LN2 / to_q / attention and enter
+            # the to_out GEMM as zero A rows (no main loop for tiles that lie entirely inside them)
+            r0 = nzero * HW_
+            l2 = ops.layernorm(t1[r0:], a["ln2"][0], a["ln2"][1], 1e-5, self._buf("ln", (M, c))[r0:])
+            q2 = ops.gemm(l2, a["q2"], self._buf("q2", (M, c))[r0:])
             k2, vt2 = kv[p]
-            at2 = ops.flash_attn(q2, k2, vt2, self._buf("at", (M, c)), B, H, HW_, L)
-            t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M)
+            at2 = self._buf("at", (M, c))
+            ops.flash_attn(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
+            t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0)
             # GEGLU feed-forward
             l3 = ops.layernorm(t2, a["ln3"][0], a["ln3"][1], 1e-5, self._buf("ln", (M, c)))
             ff = ops.gemm(l3, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU)

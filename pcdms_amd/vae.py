@@ -304,7 +304,12 @@ class AutoencoderKL(ModuleSurface):
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
-        """z [B,4,h,w] (already divided by scaling_factor) -> image [B,3,8h,8w] fp32."""
+        """z [B,4,h,w] (already divided by scaling_factor) -> image [B,3,8h,8w] fp32 (a fresh tensor: two calls never alias)."""
+        img = self._decode_buf(z)[:, : self.config.out_channels].clone()
+        return DecoderOutput(img) if return_dict else (img,)
+
+    def _decode_buf(self, z: torch.Tensor) -> torch.Tensor:
+        """The decoder proper; returns the reused fp32 [B,4,H,W] buffer (3 image channels + 1 padding channel)."""
         if self._w is None:
             self._pack()
         W_, cfg = self._w, self.config
@@ -326,15 +331,13 @@ class AutoencoderKL(ModuleSurface):
         img4 = self._buf("img4", (B, 4, H, W), torch.float32)      # 3 channels + 1 padding channel
         ops.gemm(n, W_["d.conv_out"], img4, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), rows_per_batch=H * W,
                  epilogue=ops.EPI_NCHW_F32)
-        img = img4[:, : cfg.out_channels]
-        return DecoderOutput(img) if return_dict else (img,)
+        return img4
 
     @torch.no_grad()
     def decode_to_uint8(self, z: torch.Tensor) -> torch.Tensor:
         """decode + ``VaeImageProcessor.postprocess`` (ref :528-532) -> uint8 [B, H, W, 3] on the device."""
-        img = self.decode(z, return_dict=False)[0]
-        B, _, H, W = img.shape
-        base = img._base if img._base is not None else img     # the 4-channel buffer behind the view
+        base = self._decode_buf(z)
+        B, _, H, W = base.shape
         out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=self._device)
         ops._chk(_lib.lib().pcdm_image_to_uint8(base.data_ptr(), out.data_ptr(), B, base.shape[1], H * W, ops._stream(out)),
                  "pcdm_image_to_uint8")

@@ -69,7 +69,8 @@ def test_stage2_driver_flow(gpu_backend, tmp_path):
         Image.fromarray(rng.integers(0, 255, (150, 90, 3), dtype=np.uint8)).save(tmp_path / "img" / f"{n}.png")
         Image.fromarray(rng.integers(0, 255, (150, 90, 3), dtype=np.uint8)).save(tmp_path / "pose" / f"{n}_pose.jpg")
     pairs = [{"source_image": "a.jpg", "target_image": "b.jpg"}, {"source_image": "b.jpg", "target_image": "c.jpg"}]
-    for p in pairs:
+    other_first = {"source_image": "c.jpg", "target_image": "a.jpg"}
+    for p in pairs + [other_first]:
         np.save(tmp_path / "embed" / (p["source_image"].replace(".jpg", "_to_") + p["target_image"].replace(".jpg", ".npy")),
                 rng.standard_normal((1, 64)).astype(np.float32) * 0.4)
     W, H = 64, 128
@@ -85,6 +86,17 @@ def test_stage2_driver_flow(gpu_backend, tmp_path):
     grids = sorted(show.glob("*.png"))
     assert [g.name for g in grids] == ["a_to_b.png", "b_to_c.png"]
     assert Image.open(grids[0]).size == (3 * 2 * W, 2 * H)
+    # pair 2's result must not depend on WHICH pair came first (the driver re-uses one pipe / one UNet for every pair,
+    # /root/reference/stage2_batchtest_inpaint_model.py:141-200; round 1 re-used pair 1's cross-attention K/V for pair 2).
+    # Same tensor shapes => the shared generator is in the same state when pair 2 starts, so the PNG must be IDENTICAL.
+    args_b = drv.build_parser().parse_args(base[:base.index("--save_path")] + ["--save_path", str(tmp_path / "out_b")] +
+                                           base[base.index("--save_path") + 2:] + ["--json_path", str(tmp_path / "test_data.json")])
+    drv.inference(args_b, 0, [other_first, pairs[1]])
+    g_a = np.asarray(Image.open(grids[1]))
+    g_b = np.asarray(Image.open(tmp_path / "out_b" / "show_guidancescale2.0_seed42_numsteps3" / "b_to_c.png"))
+    assert np.array_equal(g_a, g_b), float(np.abs(g_a.astype(int) - g_b.astype(int)).mean())
+    g_first = np.asarray(Image.open(tmp_path / "out_b" / "show_guidancescale2.0_seed42_numsteps3" / "c_to_a.png"))
+    assert not np.array_equal(g_first[H:], np.asarray(Image.open(grids[0]))[H:])   # (the first pairs did differ)
     # "train" json: CLIP embedding of the target image, best-SSIM sample saved as the 64 x 128 target half
     (tmp_path / "train_data.json").write_text(json.dumps(pairs[:1]))
     args = drv.build_parser().parse_args(base + ["--json_path", str(tmp_path / "train_data.json"), "--calculate_metrics"])

@@ -73,3 +73,41 @@ def test_run_sharded_gloo_world2(npairs):
 def test_run_sharded_single_process():
     res = run_sharded([3, 4], _sample)
     assert torch.equal(res[1], _sample(4))
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+
+    def sample(pair):
+        return (_sample(pair)).to(f"cuda:{rank}")
+    sample.example_output = torch.zeros(2, 4, 3, 5, device=f"cuda:{rank}")
+    res = run_sharded(list(range(5)), sample)
+    ok = len(res) == 5 and all(torch.equal(r.cpu(), _sample(i)) for i, r in enumerate(res))
+    q.put((rank, ok, dist.get_world_size()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_run_sharded_rccl_world2():
+    """The same harness over RCCL (backend "nccl"), one process per GPU; needs two devices (the 1-GPU box skips)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True, 2), (1, True, 2)]

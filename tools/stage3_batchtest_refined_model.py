@@ -90,6 +90,16 @@ def inference(args, rank, select_test_datas):
     return all_ssim
 
 
+def _guidance(s: str):
+    """The reference declares ``type=int, default=2.0``: the untouched default formats as ``guidancescale2.0`` and an explicit
+    ``--guidance_scale 2`` as ``guidancescale2`` (which is what the stage-3 driver's default ``--gen_t_img_path`` expects).  Same
+    here; non-integer values (an argparse error in the reference) are accepted as floats."""
+    try:
+        return int(s)
+    except ValueError:
+        return float(s)
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="Stage-3 refinement evaluation driver (reference flags) on pcdms_amd.")
     p.add_argument("--pretrained_model_name_or_path", type=str, default="./stable-diffusion-2-1-base")
@@ -99,7 +109,7 @@ def build_parser():
     p.add_argument("--json_path", type=str, default="./datasets/deepfashing/test_data.json")
     p.add_argument("--gen_t_img_path", type=str, default="./save_data/stage2/guidancescale2_seed42_numsteps20/")
     p.add_argument("--save_path", type=str, default="./save_data/stage3")
-    p.add_argument("--guidance_scale", type=float, default=2.0)
+    p.add_argument("--guidance_scale", type=_guidance, default=2.0)   # ref: type=int, default=2.0 => "2.0" by default, "2" when given
     p.add_argument("--seed_number", type=int, default=42)
     p.add_argument("--num_inference_steps", type=int, default=20)
     p.add_argument("--img_width", type=int, default=512)
