@@ -83,7 +83,7 @@ typedef struct pcdm_gemm_params {
     int64_t ldw;       /* row stride of W in elements (0 -> K); lets an activation slice act as the [N,K] operand */
     int32_t no_pad_lo; /* conv: 1 = zero padding at the bottom/right only (taps start AT the output pixel): the VAE
                           encoder's Downsample2D(padding=0) + F.pad(0,1,0,1); 0 = symmetric padding 1 */
-    int32_t tile;      /* 0 = heuristic; 1..18 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
+    int32_t tile;      /* 0 = heuristic; 1..26 = explicit tile configuration (gemm.hip dispatch_tile), -1 if invalid for N */
     int32_t act;       /* PCDM_ACT_*: out = act(acc + bias + rowvec) + residual.  With PCDM_EPI_GEGLU: gate activation, 0 = GELU(erf) (GEGLU),
                           PCDM_ACT_SILU = SwiGLU (DINOv2 SwiGLUFFN).  SiLU: the convs of
                           ControlNetConditioningEmbedding (stage2_batchtest_inpaint_model.py:101); GELU(erf): ImageProjModel_p (:54-56) */

@@ -17,6 +17,9 @@ CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libpcdm.so"
 SOURCES = ["norm.hip", "gemm.hip", "attn.hip", "misc.hip"]
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]   # MFMA accumulators in arch VGPRs (no v_accvgpr moves)
+NO_VGPR_FORM: set = set()
+EXTRA_DEPS: dict = {}
 ARCH = "gfx950"
 
 
@@ -42,9 +45,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
     for src in SOURCES:
         s = CSRC / src
         o = LIBDIR / (src + ".o")
-        if force or _stale(o, [s, *headers]):
-            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                         "-Wno-unused-result", "-c", str(s), "-o", str(o)])
+        if force or _stale(o, [s, *headers, *[CSRC / d for d in EXTRA_DEPS.get(src, [])]]):
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+                         *([] if src in NO_VGPR_FORM else VGPR_FORM), "-Wno-unused-result", "-c", str(s), "-o", str(o)])
         objs.append(str(o))
     if jobs:   # the translation units are independent: compile them side by side (gemm.hip alone is ~1 min)
         from concurrent.futures import ThreadPoolExecutor

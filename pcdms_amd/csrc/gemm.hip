@@ -24,9 +24,9 @@
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 
-namespace {
-constexpr int BK = 64;
+#include <type_traits>
 
+namespace pcdm_gemm_detail {
 struct GemmArgs {
     const u16* a;
     const u16* a2;
@@ -57,9 +57,11 @@ struct GemmArgs {
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
     int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs
 };
+}  // namespace pcdm_gemm_detail
 
-// 16 zero bytes: the LDS-DMA source of every padded / out-of-range chunk (halo, rows >= M)
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+namespace {
+using pcdm_gemm_detail::GemmArgs;
+constexpr int BK = 64;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;
@@ -67,6 +69,58 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // gated-linear-unit epilogue: GEGLU (diffusers FeedForward, act == 0) or SwiGLU (DINOv2 SwiGLUFFN, act == PCDM_ACT_SILU)
 __device__ __forceinline__ float gate_act(float g, int act) { return act == PCDM_ACT_SILU ? silu_f(g) : gelu_erf_f(g); }
+
+// 32 bytes of zeros: the source of every epilogue operand that is absent (no bias / row vector / residual) or out of range, so
+// that the epilogue's loads are UNCONDITIONAL: a load inside `if (p.bias)` costs a branch plus an s_waitcnt vmcnt(0) of its own
+// (hipcc never batches loads across such branches), i.e. one exposed L2 / HBM round trip per operand per 8 outputs
+__device__ __attribute__((aligned(32))) const unsigned int g_zero32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+// One pass of the LDS-staged epilogue: the wave's fp32 tile (32 rows x WCOLS channels, pitch EPW) is read back row-major, 16 B
+// (8 channels) per lane; out = act(acc + bias + rowvec) + residual as bf16.  All residual loads of the pass are issued first
+// (they come from HBM), then bias (constant per lane over the pass) and the per-row work.
+template <int WCOLS, int EPW>
+__device__ __forceinline__ void epi_store_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, bool glu) {
+    constexpr int LPR = WCOLS / 8;                 // lanes per output row
+    constexpr int RPI = 64 / LPR;                  // rows per store instruction (WCOLS = 48: 10, the last 4 lanes idle)
+    constexpr int NIT = (32 + RPI - 1) / RPI;      // store instructions per pass
+    const int rl = lane / LPR, c8 = (lane - rl * LPR) * 8;
+    const int n = ncol0 + c8;
+    const bool lane_ok = rl < RPI && n < p.N;
+    const float* zf = (const float*)g_zero32;
+    const float* bp = (p.bias && !glu && lane_ok) ? p.bias + n : zf;
+    const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+    const bool res_wrap = p.res_mod < p.M;
+    u16x8 rv[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + rl, m = mrow0 + r;
+        ok[it] = lane_ok && r < 32 && m < p.M;
+        const u16* rp = (const u16*)zf;
+        if (p.residual && ok[it]) rp = p.residual + (int64_t)(res_wrap ? m % p.res_mod : m) * p.ldr + n;
+        rv[it] = *(const u16x8*)rp;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + rl, m = mrow0 + r;
+        const float* tp = zf;
+        if (p.rowvec && ok[it]) tp = p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n;
+        const f32x4 t0 = *(const f32x4*)tp, t1 = *(const f32x4*)(tp + 4);
+        const int rr = r < 32 ? r : 0;
+        const f32x4 v0 = *(const f32x4*)(ep + rr * EPW + c8), v1 = *(const f32x4*)(ep + rr * EPW + c8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e] + t0[e]; v[e + 4] += b1[e] + t1[e]; }
+        if (p.act && !glu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+        }
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e] + bf2f(rv[it][e]));
+        if (ok[it]) *(u16x8*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
+    }
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vm_then_barrier() {
@@ -98,13 +152,23 @@ __device__ __forceinline__ void wait_lds_then_barrier() {  // this wave's ds_rea
 // memory segment (LDS-DMA issue for tile t+D, 16 ds_read_b128 of tile t), two raw barriers per K-tile
 // (MI355X_MICROARCH.md "Two waves per SIMD").  Without it every wave alternates memory and matrix phases in
 // lockstep and the two pipes are used one after the other (profiles/r1_gemm_ablation.txt: full ~ noload + nomfma).
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false>
+// F = MFMA fragment edge: 32 (v_mfma_f32_32x32x16_bf16, 16 accumulator registers per fragment) or 16 (v_mfma_f32_16x16x32_bf16, 4):
+// the same FLOP rate and the same LDS bytes per FLOP for a given wave tile; F = 16 allows wave tiles that are multiples of 16
+// (96x80: the 192x320 / 96x320 block tiles, whose counts divide the 256 CUs for M = 45056 / 11264 / 2816).
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
-    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / F, FN = WN / F;
+    constexpr int KS = 512 / F;            // k per MFMA: 16 (32x32) or 32 (16x16)
+    constexpr int NKS = BK / KS;           // MFMA k-steps per K-tile
+    constexpr int CPK = KS / 8;            // 16-byte chunks per fragment row per k-step (= lanes / F)
+    constexpr int NQ = F == 32 ? 4 : 1;    // accumulator quads (4 consecutive channels of one pixel) per lane per fragment
+    constexpr int LF = F == 32 ? 5 : 4;    // log2(F)
+    static_assert((F == 32 || F == 16) && (!STAG || F == 32), "fragment shape");
+    typedef typename std::conditional<F == 32, f32x16, f32x4>::type acc_t;
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // LDS-DMA instructions per wave per K-tile (8 rows x 128 B each)
     constexpr int D = STAGES - 1;                      // prefetch distance (tiles in flight)
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 32 == 0 && WN % F == 0, "tile shape");
     PCDM_DYN_SMEM(smem);
     u16* As = (u16*)smem;                    // [STAGES][BM][64]   (unpadded, XOR-swizzled 16-byte chunks)
     u16* Bs = As + STAGES * BM * BK;         // [STAGES][BN][64]
@@ -213,19 +277,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < BI; ++j) buf_glds16(rs_w, b_off[j], (uint32_t)(k0 * 2), bs + j * 8 * BK);
     };
 
-    f32x16 acc[FN][FM];
+    acc_t acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4 * NQ; ++r) acc[i][j][r] = 0.f;
 
     const int nkt_all = p.K / BK;
     kt0 = (int)((int64_t)ksplit * nkt_all / p.split_k);
     int nkt = (int)((int64_t)(ksplit + 1) * nkt_all / p.split_k) - kt0;  // this workgroup's K-tiles
     if (!CONV && m0 + BM <= p.zero_rows) nkt = 0;   // the whole A tile is declared zero: epilogue only (bias + residual)
-    const int frow = lane & 31, fsw = (lane >> 1) & 7, fhalf = lane >> 5;  // (row>>1)&7 == (lane>>1)&7: tile rows are 32-aligned
+    // fragment reads: lane -> row (lane % F) of the fragment, 16-byte chunk (lane / F) of the k-step; (row>>1)&7 == (lane>>1)&7
+    // because fragment rows are F-aligned (F = 16: ((lane & 15) >> 1) == (lane >> 1) & 7)
+    const int frow = lane & (F - 1), fsw = (lane >> 1) & 7, fhalf = lane >> LF;
     if constexpr (STAG) {
         static_assert(NW == 8 && D == 2, "staggered schedule: 8 waves, 3 stages");
         constexpr int PW = AI + BI;  // LDS-DMA instructions per wave per K-tile
@@ -290,21 +356,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                 // k-step ks (pinned with a scheduling barrier) so they get the whole MFMA window to return
                 u16x8 xf[2][FM], wf[2][FN];
                 auto load_frags = [&](int ks, int b) {
-                    const int co = ((ks * 2 + fhalf) ^ fsw) * 8;
+                    const int co = ((ks * CPK + fhalf) ^ fsw) * 8;
     #pragma unroll
-                    for (int j = 0; j < FM; ++j) xf[b][j] = *(const u16x8*)(as + j * 32 * BK + co);
+                    for (int j = 0; j < FM; ++j) xf[b][j] = *(const u16x8*)(as + j * F * BK + co);
     #pragma unroll
-                    for (int i = 0; i < FN; ++i) wf[b][i] = *(const u16x8*)(bs + i * 32 * BK + co);
+                    for (int i = 0; i < FN; ++i) wf[b][i] = *(const u16x8*)(bs + i * F * BK + co);
                 };
                 load_frags(0, 0);
     #pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks) {
-                    if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (ks + 1 < NKS) load_frags(ks + 1, (ks + 1) & 1);
                     PCDM_SCHED_BARRIER();
     #pragma unroll
                     for (int i = 0; i < FN; ++i)
     #pragma unroll
-                        for (int j = 0; j < FM; ++j) acc[i][j] = mfma_32x32x16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j]);
+                        for (int j = 0; j < FM; ++j) {
+                            if constexpr (F == 32) acc[i][j] = mfma_32x32x16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j]);
+                            else acc[i][j] = mfma_16x16x32(wf[ks & 1][i], xf[ks & 1][j], acc[i][j]);
+                        }
                     PCDM_SCHED_BARRIER();
                 }
             }
@@ -313,20 +382,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         }
     }
 
-    // ---- epilogue: lane holds, per (fn, fm, quad), channels n..n+3 of row m
-    const int half = lane >> 5;
+    // ---- epilogue: lane holds, per (fn, fm, quad rg), channels n..n+3 of the pixel row (lane % F) of fragment row fm;
+    // channel offset of quad rg inside its fragment: 8 rg + 4 (lane >> 5) for 32x32, 4 (lane >> 4) for 16x16
+    const int half = lane >> LF;
+    const int prow = lane & (F - 1);
+    constexpr int QS = F == 32 ? 8 : 0;   // channel stride between the quads of one lane
     if (p.split_k > 1) {  // raw fp32 partial sums; bias / temb / residual are applied by the reduce kernel
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
-            const int m = m0 + wm * WM + j * 32 + (lane & 31);
+            const int m = m0 + wm * WM + j * F + prow;
             if (m >= p.M) continue;
             float* wr = p.ws + ((int64_t)ksplit * p.M + m) * p.Npad + n0 + wn * WN + 4 * half;
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
+                for (int rg = 0; rg < NQ; ++rg) {
                     f32x4 v = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
-                    *(f32x4*)(wr + i * 32 + 8 * rg) = v;
+                    *(f32x4*)(wr + i * F + QS * rg) = v;
                 }
         }
         return;
@@ -336,135 +408,123 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     // row-major, so that every global access of the epilogue is a full 16 B per lane / whole 128-byte lines:
     // residual loads and bf16 stores.  Measured on the thin-K linears (K = 320): the direct quad stores
     // sustained only ~1.4 TB/s.  Single rounding is preserved (fp32 until the final convert).
-    if ((p.epilogue == PCDM_EPI_STORE || (p.epilogue == PCDM_EPI_GEGLU && FN == 2)) && (p.N & 7) == 0 && (p.ldo & 7) == 0 &&
+    // GEGLU: the packed weight rows alternate [32 h | 32 gate], so a 64-wide wave tile holds 32 outputs: h in its fragment columns
+    // [0, FN/2), the matching gates in [FN/2, FN)
+    constexpr bool GLU_OK = WN == 64;
+    if ((p.epilogue == PCDM_EPI_STORE || (p.epilogue == PCDM_EPI_GEGLU && GLU_OK)) && (p.N & 7) == 0 && (p.ldo & 7) == 0 &&
         (!p.residual || (p.ldr & 7) == 0)) {
         const bool geglu = p.epilogue == PCDM_EPI_GEGLU;
-        constexpr int EPW = WN + 4;                       // fp32 row pitch (conflict-free ds_write_b128)
-        __syncthreads();                                  // every wave is done with the operand stages
-        float* ep = (float*)smem + wave * (32 * EPW);     // wave-private 32 x WN tile
-        const int wno = geglu ? WN / 2 : WN;              // output columns of this wave
-        const int lpr = wno / 8;                          // lanes per output row (16 B each)
-        const int rpi = 64 / lpr;                         // rows per store instruction
-        const int ncol0 = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
+        // staged in passes of 32 pixel rows x <= 64 channels (one 128-byte line of bf16 per row): RB fragment rows x CG fragment columns
+        constexpr int RB = 32 / F;                         // fragment rows per pass
+        constexpr int CGM = 64 / F;                        // fragment columns per full pass
+        constexpr int CG = FN < CGM ? FN : CGM;
+        constexpr int EPW = CG * F + 4;                    // fp32 row pitch (conflict-free ds_write_b128)
+        __syncthreads();                                   // every wave is done with the operand stages
+        float* ep = (float*)smem + wave * (32 * EPW);      // wave-private 32 x (CG*F) tile
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            // 1. quads -> LDS [row = pixel (lane&31)][col = channel]
-            if (geglu) {
+        for (int jb = 0; jb < WM / 32; ++jb) {
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int nl = 8 * rg + 4 * half;
-                    const f32x4 bh = *(const f32x4*)(p.bias + n0 + wn * WN + nl);
-                    const f32x4 bg = *(const f32x4*)(p.bias + n0 + wn * WN + nl + 32);
-                    f32x4 v;
+            for (int i0 = 0; i0 < FN; i0 += CG) {
+                const int ng = (FN - i0) < CG ? (FN - i0) : CG;   // fragment columns in this pass (the last pass may be narrower)
+                const int ncol0 = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN + i0 * F;
+                // 1. quads -> LDS [row = pixel][col = channel]
+                if (geglu) {
+                    if constexpr (GLU_OK) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (acc[0][j][4 * rg + e] + bh[e]) * gate_act(acc[FN - 1][j][4 * rg + e] + bg[e], p.act);
-                    *(f32x4*)(ep + (lane & 31) * EPW + nl) = v;
+                        for (int jj = 0; jj < RB; ++jj)
+#pragma unroll
+                            for (int i = 0; i < FN / 2; ++i)
+#pragma unroll
+                                for (int rg = 0; rg < NQ; ++rg) {
+                                    const int nl = i * F + QS * rg + 4 * half;   // 0..31 within the wave's 32 outputs
+                                    const f32x4 bh = *(const f32x4*)(p.bias + n0 + wn * WN + nl);
+                                    const f32x4 bg = *(const f32x4*)(p.bias + n0 + wn * WN + nl + 32);
+                                    const acc_t& ah = acc[i][jb * RB + jj];
+                                    const acc_t& ag = acc[i + FN / 2][jb * RB + jj];
+                                    f32x4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * gate_act(ag[4 * rg + e] + bg[e], p.act);
+                                    *(f32x4*)(ep + (jj * F + prow) * EPW + nl) = v;
+                                }
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < RB; ++jj)
+#pragma unroll
+                        for (int i = 0; i < CG; ++i) {
+                            if (i0 + i >= FN) break;
+#pragma unroll
+                            for (int rg = 0; rg < NQ; ++rg) {
+                                const acc_t& a_ = acc[i0 + i < FN ? i0 + i : 0][jb * RB + jj];
+                                const f32x4 v = {a_[4 * rg], a_[4 * rg + 1], a_[4 * rg + 2], a_[4 * rg + 3]};
+                                *(f32x4*)(ep + (jj * F + prow) * EPW + i * F + QS * rg + 4 * half) = v;
+                            }
+                        }
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < FN; ++i)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const f32x4 v = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
-                        *(f32x4*)(ep + (lane & 31) * EPW + i * 32 + 8 * rg + 4 * half) = v;
-                    }
+                PCDM_WAVE_SYNC();
+                // 2. row-major read-back (same wave: LDS ops complete in order), fused epilogue, 16-byte stores
+                const int mrow0 = m0 + wm * WM + jb * 32;
+                if (geglu) epi_store_pass<32, EPW>(p, ep, lane, mrow0, ncol0, true);
+                else if (ng * F == 64) epi_store_pass<64, EPW>(p, ep, lane, mrow0, ncol0, false);
+                else if (ng * F == 32) epi_store_pass<32, EPW>(p, ep, lane, mrow0, ncol0, false);
+                else if (ng * F == 16) epi_store_pass<16, EPW>(p, ep, lane, mrow0, ncol0, false);
+                else epi_store_pass<48, EPW>(p, ep, lane, mrow0, ncol0, false);
+                PCDM_WAVE_SYNC();   // this pass's reads precede the next pass's writes
+                if (geglu) break;   // (one pass holds the wave's 32 outputs h * act(gate))
             }
-            PCDM_WAVE_SYNC();
-            // 2. row-major read-back (same wave: LDS ops complete in order), fused epilogue, 16-byte stores
-            for (int r0 = 0; r0 < 32; r0 += rpi) {
-                const int r = r0 + lane / lpr, c8 = (lane % lpr) * 8;
-                const int m = m0 + wm * WM + j * 32 + r, n = ncol0 + c8;
-                if (r < 32 && m < p.M && n < p.N) {
-                    const f32x4 v0 = *(const f32x4*)(ep + r * EPW + c8), v1 = *(const f32x4*)(ep + r * EPW + c8 + 4);
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    if (!geglu && p.bias) {
-                        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
-                    }
-                    if (p.rowvec) {
-                        const float* tv = p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n;
-                        const f32x4 t0 = *(const f32x4*)tv, t1 = *(const f32x4*)(tv + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[e + 4] += t1[e]; }
-                    }
-                    if (p.act && !geglu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
-                    }
-                    if (p.residual) {
-                        const u16x8 rv = *(const u16x8*)(p.residual + (int64_t)(m % p.res_mod) * p.ldr + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
-                    }
-                    u16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-                    *(u16x8*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
-                }
-            }
-            PCDM_WAVE_SYNC();   // pass j's reads precede pass j+1's writes
         }
         return;
     }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * WM + j * 32 + (lane & 31);
+        const int m = m0 + wm * WM + j * F + prow;
         if (m >= p.M) continue;
         const int bidx = m / p.rows_per_batch;
         const int tok = m - bidx * p.rows_per_batch;
         const int64_t rrow = p.residual ? (int64_t)(m % p.res_mod) * p.ldr : 0;
         if (p.epilogue == PCDM_EPI_GEGLU) {
-            if (FN == 2) {
+            if constexpr (GLU_OK) {
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int nl = 8 * rg + 4 * half;           // 0..31 within the wave's 32 outputs
-                    const int nh = n0 + wn * WN + nl;           // packed row of h
-                    const int ng = nh + 32;                     // packed row of gate
-                    const int no = (n0 + wn * WN) / 2 + nl;     // output channel
-                    if (no >= p.N) continue;
-                    const f32x4 bh = *(const f32x4*)(p.bias + nh), bg = *(const f32x4*)(p.bias + ng);
-                    u16x4 o;
+                for (int i = 0; i < FN / 2; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float hval = acc[0][j][4 * rg + e] + bh[e];
-                        const float gval = acc[FN - 1][j][4 * rg + e] + bg[e];
-                        o[e] = f2bf(hval * gate_act(gval, p.act));
+                    for (int rg = 0; rg < NQ; ++rg) {
+                        const int nl = i * F + QS * rg + 4 * half;  // 0..31 within the wave's 32 outputs
+                        const int nh = n0 + wn * WN + nl;           // packed row of h
+                        const int ng = nh + 32;                     // packed row of gate
+                        const int no = (n0 + wn * WN) / 2 + nl;     // output channel
+                        if (no >= p.N) continue;
+                        const f32x4 bh = *(const f32x4*)(p.bias + nh), bg = *(const f32x4*)(p.bias + ng);
+                        u16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float hval = acc[i][j][4 * rg + e] + bh[e];
+                            const float gval = acc[i + FN / 2][j][4 * rg + e] + bg[e];
+                            o[e] = f2bf(hval * gate_act(gval, p.act));
+                        }
+                        *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + no) = o;
                     }
-                    *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + no) = o;
-                }
             }
             continue;
         }
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wn * WN + i * 32 + 8 * rg + 4 * half;
+            for (int rg = 0; rg < NQ; ++rg) {
+                const int n = n0 + wn * WN + i * F + QS * rg + 4 * half;
                 if (n >= p.N) continue;
+                // unconditional loads (absent operands read zeros): see g_zero32
+                const f32x4 bv = *(const f32x4*)(p.bias ? p.bias + n : (const float*)g_zero32);
+                const f32x4 tv = *(const f32x4*)(p.rowvec ? p.rowvec + (int64_t)bidx * p.ldrv + n : (const float*)g_zero32);
+                const u16x4 rv = *(const u16x4*)(p.residual ? p.residual + rrow + n : (const u16*)g_zero32);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e];
-                if (p.bias) {
-                    const f32x4 bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                }
-                if (p.rowvec) {
-                    const f32x4 tv = *(const f32x4*)(p.rowvec + (int64_t)bidx * p.ldrv + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += tv[e];
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bv[e] + tv[e];
                 if (p.act) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
                 }
-                if (p.residual) {
-                    const u16x4 rv = *(const u16x4*)(p.residual + rrow + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
-                }
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
                 if (p.epilogue == PCDM_EPI_NCHW_F32) {
                     float* o = (float*)p.out;
 #pragma unroll
@@ -492,6 +552,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)p.M * nq) return;
     const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+    // epilogue operands first (unconditional loads; absent ones read zeros, see g_zero32): they return while the slabs are summed
+    const f32x4 bv = *(const f32x4*)(p.bias ? p.bias + n : (const float*)g_zero32);
+    const f32x4 tv = *(const f32x4*)(p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n : (const float*)g_zero32);
+    const u16x4 rv = *(const u16x4*)(p.residual ? p.residual + (int64_t)(m % p.res_mod) * p.ldr + n : (const u16*)g_zero32);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     // slabs summed in a fixed order, four independent 16-byte loads in flight at a time (a one-load-per-iteration loop
     // pays one L2 / HBM round trip per slab)
@@ -507,39 +571,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         v += t3;
     }
     for (; s < p.split_k; ++s) v += *(const f32x4*)(wp + s * slab);
-    if (p.bias) v += *(const f32x4*)(p.bias + n);
-    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n);
+    v += bv;
+    v += tv;
     if (p.act) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
     }
-    if (p.residual) {
-        const u16x4 rv = *(const u16x4*)(p.residual + (int64_t)(m % p.res_mod) * p.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
-    }
+    for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
     u16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
     *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     // operand ring, or the wave-private fp32 epilogue tiles (32 x (WN + 4) floats per wave) if those need more
     constexpr int smem_ops = STAGES * (BM + BN) * BK * (int)sizeof(u16);
-    constexpr int smem_epi = WGM * WGN * 32 * (BN / WGN + 4) * (int)sizeof(float);
+    constexpr int FN_ = BN / WGN / F, CGM_ = 64 / F;
+    constexpr int smem_epi = WGM * WGN * 32 * ((FN_ < CGM_ ? FN_ : CGM_) * F + 4) * (int)sizeof(float);
     constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG>,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
+    if (a.Npad % BN) return -1;                                        // the N tiles must cover Npad exactly
+    if (a.epilogue == PCDM_EPI_GEGLU && BN / WGN != 64) return -1;   // GEGLU pairs [32 h | 32 gate] need a 64-wide wave tile
     GemmArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = a.Npad / BN;
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG>), dim3(g.tiles_m * g.tiles_n * g.split_k),
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F>), dim3(g.tiles_m * g.tiles_n * g.split_k),
                 dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
     if (g.split_k > 1) {
@@ -556,6 +620,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 template <bool CONV>
 int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
     switch (tile) {
+#ifndef PCDM_DEV_NEW_TILES_ONLY   // (developer builds of a few instantiations: tools/ubench; never defined for the product)
         case 1: return launch_gemm<256, 128, 4, 2, 3, CONV>(a, st);   // 8 waves, 144 KiB, 1 block / CU
         case 2: return launch_gemm<64, 64, 2, 2, 2, CONV>(a, st);     // 4 waves,  32 KiB, 4+ blocks / CU
         case 3: return launch_gemm<256, 64, 4, 2, 2, CONV>(a, st);    // 8 waves,  80 KiB, 2 blocks / CU
@@ -579,6 +644,24 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         // 128x128 with EIGHT waves (32x64 each): the same 64 KiB and 2 blocks / CU as tile 4, but 4 waves per SIMD to hide
         // LDS / MFMA-result latency (the 4-wave tiles run 2 waves per SIMD)
         case 18: return launch_gemm<128, 128, 4, 2, 2, CONV>(a, st);
+#endif
+        // Full-row tiles for N = 320 k (every UNet level: 320 / 640 / 960 / 1280 / 1920 / 3840 channels): BN = 320, wave tile
+        // 64..128 x 160.  With BN = 64 the A tile is re-fetched by 5 N tiles and the loop sits on the L2 -> LDS rate
+        // (~19 TB/s measured) and the LDS read rate (1.5 ds_read_b128 per MFMA); a 64x160 wave tile needs 0.7 reads per MFMA
+        // and 2.8x fewer staged bytes per FLOP.
+        case 19: return launch_gemm<256, 320, 4, 2, 2, CONV>(a, st);   // 8 waves (64x160 each), 144 KiB, 1 block / CU
+        case 20: return launch_gemm<128, 320, 2, 2, 2, CONV>(a, st);   // 4 waves (64x160 each), 112 KiB, 1 block / CU
+        // (192x320 / 256x320 with FOUR waves of 96x160 / 128x160 32x32 fragments -- one wave per SIMD, AGPR accumulators -- were tried
+        //  and dropped: hipcc 7.2 crashes in 'AMDGPU Rewrite AGPR-Copy-MFMA' under -amdgpu-mfma-vgpr-form=1 and spills ~2 KiB per
+        //  lane without it)
+        // 16x16x32 fragments: wave tile 96x80.  192-row tiles: M = 45056 -> 235 workgroups (N = 320), M = 11264 -> 59 x 2 (N = 640),
+        // M = 2816 -> 15 x 4 (N = 1280); 96-row tiles: M = 11264 -> 118 x 2 = 236 -- all within 8 % of the 256 CUs.
+        case 21: return launch_gemm<192, 320, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves, 128 KiB, 1 block / CU
+        case 22: return launch_gemm<96, 320, 1, 4, 2, CONV, false, 16>(a, st);    // 4 waves, 104 KiB, 1 block / CU
+        case 25: return launch_gemm<96, 320, 1, 4, 3, CONV, false, 16>(a, st);    // 4 waves, 156 KiB, 1 block / CU, two tiles in flight
+        case 26: return launch_gemm<192, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96x64 each: GEGLU-capable), 112 KiB
+        case 23: return launch_gemm<128, 160, 2, 1, 2, CONV>(a, st);   // 2 waves (64x160 each), 72 KiB, 2 blocks / CU
+        case 24: return launch_gemm<128, 160, 2, 1, 3, CONV>(a, st);   // 2 waves, 108 KiB, 1 block / CU, two tiles in flight
         default: return -1;
     }
 }
@@ -644,7 +727,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     int tile = p->tile & 0xff;
     const bool n128 = p->Npad % 128 == 0;
     const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11 || tile == 18;
-    if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile
+    if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile (19+: launch_gemm checks)
     if (tile == 0) {
         const int64_t t256 = (int64_t)((p->M + 255) / 256) * (p->Npad / 128);
         const int64_t t128 = (int64_t)((p->M + 127) / 128) * (p->Npad / 128);

@@ -155,6 +155,32 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(u16x8 a, u16x8 b, f32x16 c) {
 #endif
 }
 
+// 16x16x32 bf16:  A lane l -> row (l&15), k = 8*(l>>4)+e ;  B lane l -> col (l&15), same k ;
+//                 D lane l, reg r -> col (l&15), row r + 4*(l>>4).
+__device__ __forceinline__ f32x4 mfma_16x16x32(u16x8 a, u16x8 b, f32x4 c) {
+#ifdef PCDM_EMU
+    struct P { u16 a[8], b[8]; } p;
+    for (int e = 0; e < 8; ++e) { p.a[e] = a[e]; p.b[e] = b[e]; }
+    const char* all = emu::wave_exchange(&p, sizeof(p));
+    const int l = emu::lane_id(), j = l & 15, hh = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = r + 4 * hh;
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const P* pa = (const P*)(all + (i + 16 * (k >> 3)) * emu::kSlot);
+            const P* pb = (const P*)(all + (j + 16 * (k >> 3)) * emu::kSlot);
+            s += bf2f(pa->a[k & 7]) * bf2f(pb->b[k & 7]);
+        }
+        d[r] = s;
+    }
+    return d;
+#else
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
 // ---- inter-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16) ----------------
 #ifdef PCDM_EMU
 __device__ __forceinline__ void pcdm_drain_vmem() {}

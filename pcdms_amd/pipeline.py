@@ -305,8 +305,7 @@ class Stage2_InpaintDiffusionPipeline:
             self._graph = None
         st["step"].zero_()
         self._st, self._graph_key = st, key
-        simple_cb = callback is None
-        if use_graph and dev.type == "cuda" and simple_cb:
+        if use_graph and dev.type == "cuda":
             if self._graph is None or self._st.get("g_captured") != g:
                 # warm-up step (allocates every scratch buffer, autotunes unseen GEMM shapes), then capture
                 lat0 = st["lat"].clone()
@@ -324,8 +323,10 @@ class Stage2_InpaintDiffusionPipeline:
                 st["g_captured"] = g
                 w_gen = (id(unet), getattr(unet, "_pack_gen", 0), ops.workspace_generation(dev))   # (the warm-up may have grown it)
             st["w_gen"] = w_gen
-            for _ in range(n):
+            for i in range(n):
                 self._graph.replay()
+                if callback is not None and i % callback_steps == 0:   # (stream-ordered copy of the live latent buffer)
+                    callback(i, timesteps[i], st["lat"].clone())
         else:
             st["w_gen"] = w_gen
             for i in range(n):

@@ -1,0 +1,143 @@
+"""Full-size, full-length parity for BASELINE.json configs[1] (and the per-GPU share of configs[2]) against the committed
+fp32-oracle fixture ``tests/golden/fullsize_config2.npz`` (made by ``tests/golden/make_fullsize_config2_fixture.py`` in the
+build container: 868.9 M-parameter seeded UNet with random norm affines, latent 64x88, N = 4 => UNet batch 8, 50 DDIM
+steps, guidance 2.0, then the full-size VAE decode to uint8 canvases).
+
+What is compared (reference: /root/reference/src/pipelines/stage2_inpaint_pipeline.py:494-532):
+
+* ONE forward at the oracle's own state -- eps at steps 0 / 10 / 25 / 49 with the fixture's latents as input (M = 45 056
+  rows through every GEMM / conv tile the bench uses): rel-L2 <= FWD_TOL;
+* the 50-step hipGraph trajectory from the same initial latents -- latents before steps 10 / 25 / 49 and the final latents:
+  rel-L2 <= TRAJ_TOL (bf16 activations between kernels vs the fp32 oracle, error carried through 50 steps);
+* uint8 canvases after VAE decode (HIP VAE on the HIP latents vs oracle VAE on the oracle latents): mean |diff| <= PIX_TOL
+  levels of 255, and per-canvas mean within PIX_MEAN_TOL levels;
+* configs[2]'s per-GPU share: one forward at N = 8 (UNet batch 16).
+
+Tolerances are stated here and were set from the measured values on MI355X (recorded in DESIGN.md §5)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.pipeline import build_conditioning, synth_inputs
+from oracle.schedulers import DDIMOracle
+from oracle.unet import UNetConfig, synth_state_dict
+from pcdms_amd.pipeline import Stage2_InpaintDiffusionPipeline
+from pcdms_amd.schedulers import DDIMScheduler
+from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
+from tests.test_schedulers import SD21
+from tests.test_unet import _kwargs
+
+FIXTURE = Path(__file__).resolve().parent / "golden" / "fullsize_config2.npz"
+FWD_TOL = 1.5e-2      # one forward, rel-L2 of the guided eps (round 1 measured 0.78e-2 on a builder-side run)
+TRAJ_TOL = 3e-2       # latents along / at the end of the 50-step trajectory
+PIX_TOL = 3.0         # mean absolute difference in uint8 levels over a canvas
+PIX_MEAN_TOL = 1.5    # |mean(canvas) - mean(oracle canvas)| in uint8 levels
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), torch.as_tensor(np.asarray(b, dtype=np.float32))
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def full(request):
+    if not FIXTURE.exists():
+        pytest.fail(f"{FIXTURE} missing: run tests/golden/make_fullsize_config2_fixture.py")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pcdms_amd import _lib
+    _lib.load()
+    fx = np.load(FIXTURE)
+    assert str(fx["torch_version"]) == torch.__version__, "seeded CPU generators: the fixture was made with another torch build"
+    cfg = UNetConfig()
+    sd = synth_state_dict(cfg, seed=0, random_affine=True)
+    dev = torch.device("cuda:0")
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(dev)
+    return fx, cfg, m, dev
+
+
+def _guided_eps(m, cfg, inp, lat, t, N, dev):
+    c = build_conditioning(inp["masked_latents"], inp["s_img_proj_f"], inp["st_pose_f"], inp["pred_t_img_embed"], N, True)
+    x = torch.cat([lat] * 2)
+    eps = m(torch.cat([x, c["mask"], c["masked_latents"]], 1).to(dev), t, encoder_hidden_states=c["feature_f"].to(dev),
+            class_labels=c["prior_embed"].to(dev), my_pose_cond=c["pose_cond"].to(dev)).sample.float().cpu()
+    u, cn = eps.chunk(2)
+    return u + 2.0 * (cn - u)
+
+
+@pytest.mark.gpu
+def test_single_forward_at_oracle_states(full):
+    fx, cfg, m, dev = full
+    N, h, w = 4, 64, 88
+    inp = synth_inputs(cfg, h, w, N)
+    sch = DDIMOracle()
+    sch.set_timesteps(int(fx["steps"]))
+    rels = {}
+    for i in [int(v) for v in fx["check"]]:
+        eps = _guided_eps(m, cfg, inp, torch.from_numpy(fx[f"lat_{i}"]), sch.timesteps[i], N, dev)
+        rels[i] = _rel(eps, fx[f"eps_{i}"])
+    print("full-size single-forward rel-L2 (guided eps) per step:", {k: round(v, 5) for k, v in rels.items()})
+    assert max(rels.values()) <= FWD_TOL, rels
+
+
+@pytest.mark.gpu
+def test_50_step_trajectory_and_pixels(full):
+    fx, cfg, m, dev = full
+    N, h, w = 4, 64, 88
+    steps = int(fx["steps"])
+    inp = synth_inputs(cfg, h, w, N)
+    assert np.array_equal(inp["latents"].numpy(), fx["lat_0"])     # same seeded inputs as the fixture run
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    seen = {}
+    out = pipe(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
+               st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
+               num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent",
+               callback=lambda i, t, lat: seen.__setitem__(i + 1, lat)).latents          # hipGraph replay + per-step snapshot
+    assert pipe._graph is not None and len(seen) == steps
+    rels = {i: _rel(seen[i], fx[f"lat_{i}"]) for i in [int(v) for v in fx["check"]] if i > 0}
+    rels["final"] = _rel(out, fx["lat_final"])
+    print("full-size 50-step trajectory rel-L2 (latents before step i / final):", {k: round(v, 5) for k, v in rels.items()})
+    assert max(rels.values()) <= TRAJ_TOL, rels
+    # a second call with the graph already captured reproduces the first bit for bit
+    out2 = pipe(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
+                st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
+                num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent").latents
+    assert torch.equal(out, out2)
+    # ---- pixels: VAE decode + VaeImageProcessor.postprocess (ref :528-532) on the HIP latents
+    from oracle import vae as OV
+    from pcdms_amd.vae import AutoencoderKL
+    vcfg = OV.VAEConfig()
+    vae = AutoencoderKL()
+    vae.load_state_dict(OV.synth_state_dict(vcfg, 0))
+    vae.to(dev)
+    u8 = vae.decode_to_uint8(out / vcfg.scaling_factor).cpu().numpy()
+    assert u8.shape == (N, h * 8, w * 8, 3)
+    pix = {k: float(np.abs(u8[k].astype(np.int32) - fx[f"img_{k}"].astype(np.int32)).mean()) for k in (0, 3)}
+    means = np.abs(u8.reshape(N, -1).astype(np.float64).mean(1) - fx["img_mean"])
+    # the VAE alone, on the ORACLE's final latents (separates decoder error from trajectory error)
+    u8o = vae.decode_to_uint8(torch.from_numpy(fx["lat_final"]).to(dev) / vcfg.scaling_factor).cpu().numpy()
+    pix_vae = {k: float(np.abs(u8o[k].astype(np.int32) - fx[f"img_{k}"].astype(np.int32)).mean()) for k in (0, 3)}
+    print("full-size uint8 canvases: mean|diff| levels", {k: round(v, 3) for k, v in pix.items()}, "VAE alone", {k: round(v, 3) for k, v in pix_vae.items()},
+          "canvas-mean diff", np.round(means, 3).tolist())
+    assert max(pix.values()) <= PIX_TOL and max(pix_vae.values()) <= PIX_TOL and means.max() <= PIX_MEAN_TOL, (pix, pix_vae, means)
+
+
+@pytest.mark.gpu
+def test_batch16_forward_configs2_share(full):
+    fx, cfg, m, dev = full
+    if "b16_eps" not in fx:
+        pytest.skip("fixture made with --no-b16")
+    N, h, w = 8, 64, 88
+    inp = synth_inputs(cfg, h, w, N)
+    sch = DDIMOracle()
+    sch.set_timesteps(int(fx["steps"]))
+    eps = _guided_eps(m, cfg, inp, inp["latents"], sch.timesteps[0], N, dev)
+    r = _rel(eps, fx["b16_eps"])
+    print("full-size UNet-batch-16 forward rel-L2:", round(r, 5))
+    assert r <= FWD_TOL, r

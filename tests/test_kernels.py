@@ -152,7 +152,7 @@ def test_gemm_two_source_and_broadcast_residual(backend):
 
 def test_gemm_geglu(backend):
     dev = backend.device
-    M, K, D = (70, 64, 96) if backend.is_emu else (11264, 640, 2560)
+    M, K, D = (70, 64, 128) if backend.is_emu else (11264, 640, 2560)
     a = rnd(M, K, seed=30)
     w = rnd(2 * D, K, seed=31, scale=1 / math.sqrt(K))
     bias = torch.randn(2 * D, generator=torch.Generator().manual_seed(32)) * 0.5
@@ -195,14 +195,16 @@ def test_gemm_split_vt_and_nchw(backend):
 def test_gemm_narrow_tiles_geglu_and_conv(backend):
     """tiles 13-16 (BN = 64, one wave column, 64x64 wave tiles): GEGLU pairs inside one wave, conv gather, M tails."""
     dev = backend.device
-    M, K, D = (70, 64, 96) if backend.is_emu else (11264, 640, 2560)
+    M, K, D = (70, 64, 128) if backend.is_emu else (11264, 640, 2560)
     a = rnd(M, K, seed=30)
     w = rnd(2 * D, K, seed=31, scale=1 / math.sqrt(K))
     bias = torch.randn(2 * D, generator=torch.Generator().manual_seed(32)) * 0.5
     pw = ops.pack_geglu(w.float(), bias, dev)
     pr = a.float() @ w.float().t() + bias
     h, g = pr.chunk(2, -1)
-    for tile in (13, 16) if backend.is_emu else (13, 14, 15, 16):
+    for tile in (13, 16, 26) if backend.is_emu else (13, 14, 15, 16, 26):
+        if pw.Npad % ops.TILE_SHAPES[tile][1]:
+            continue
         out = torch.empty(M, D, dtype=BF16, device=dev)
         ops.gemm(a.to(dev), pw, out, epilogue=ops.EPI_GEGLU, tile=tile)
         backend.sync()
@@ -377,3 +379,74 @@ def test_assemble_cfg_step_lincomb_layout(backend):
     ops.lincomb(y, [xp, eo, noise.to(dev)], [0.5, -2.0, 3.0])
     backend.sync()
     assert torch.allclose(y.cpu(), 0.5 * xp.cpu() - 2 * eo.cpu() + 3 * noise, atol=1e-5)
+
+
+def test_gemm_full_row_tiles_and_zero_rows(backend):
+    """Tiles 19 / 20 / 23 / 24 (BN = 320 or 160, wave tile 64x160: five 32-wide fragment columns, LDS-staged epilogue in passes of
+    two + two + one) and 21 / 22 / 25 (16x16x32 fragments, wave tile 96x80: passes of 64 + 16 channels): linear with bias / residual / row vector, the qkv split epilogue (V^T), a conv with M tail, split-K; and
+    ``zero_rows`` (A rows declared all-zero: not read, tiles entirely inside run the epilogue only) on old and new tiles."""
+    dev = backend.device
+    tiles = (19, 23, 21, 22) if backend.is_emu else (19, 20, 21, 22, 23, 24, 25)
+    M, K, N = (300, 128, 320) if backend.is_emu else (5632 * 2 + 100, 640, 640)
+    a = rnd(M, K, seed=60)
+    w = rnd(N, K, seed=61, scale=1 / math.sqrt(K))
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(62))
+    res = rnd(M, N, seed=63)
+    rpb = M // 2
+    rowvec = torch.randn(2, N, generator=torch.Generator().manual_seed(64))
+    pw = ops.pack_linear(w.float(), bias, dev)
+    ref = a.float() @ w.float().t() + bias + res.float() + rowvec.repeat_interleave(rpb, 0)
+    for tile in tiles:
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.gemm(a.to(dev), pw, out, rowvec=rowvec.to(dev), rows_per_batch=rpb, residual=res.to(dev), res_mod=M, tile=tile)
+        backend.sync()
+        close(out, ref)
+    # zero_rows: rows [0, z) of A hold GARBAGE that must not be read; out = bias + residual there
+    for tile, z in ((19, 256), (21, 100), (3, 256), (4, 130)) if backend.is_emu else ((19, M // 2), (20, 1000), (21, M // 2), (22, 777), (13, M // 2), (18, 4321), (0, M // 2)):
+        if pw.Npad % ops.TILE_SHAPES.get(tile, (0, 64))[1]:
+            continue
+        ag = a.clone()
+        ag[:z] = float("nan")
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.gemm(ag.to(dev), pw, out, residual=res.to(dev), res_mod=M, tile=tile, zero_rows=z)
+        backend.sync()
+        az = a.float().clone()
+        az[:z] = 0
+        close(out, az @ w.float().t() + bias + res.float())
+    # split-K on a full-row tile
+    if not backend.is_emu:
+        a2, w2 = rnd(704, 11520, seed=65), rnd(1280, 11520, seed=66, scale=1 / math.sqrt(11520))
+        pw2 = ops.pack_linear(w2.float(), None, dev)
+        out = torch.empty(704, 1280, dtype=BF16, device=dev)
+        for tile, sk in ((19, 8), (21, 4), (22, 3)):
+            ops.gemm(a2.to(dev), pw2, out, tile=tile, split_k=sk)
+            backend.sync()
+            close(out, a2.float() @ w2.float().t())
+    # fused q|k|v projection with the V^T epilogue (N = 3C = 960 at level 0) on a full-row tile
+    Bq, T, C = (2, 20, 320) if backend.is_emu else (8, 5632, 320)
+    x = rnd(Bq * T, C if not backend.is_emu else 64, seed=67)
+    wq = rnd(3 * C, x.shape[1], seed=68, scale=1 / math.sqrt(x.shape[1]))
+    pwq = ops.pack_linear(wq.float(), None, dev)
+    qk = torch.empty(Bq * T, 2 * C, dtype=BF16, device=dev)
+    Tp = (T + 7) // 8 * 8
+    vt = torch.zeros(Bq, C, Tp, dtype=BF16, device=dev)
+    pr = x.float() @ wq.float().t()
+    for tile in (19, 21):
+        qk.zero_(); vt.zero_()
+        ops.gemm(x.to(dev), pwq, qk, rows_per_batch=T, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * C, tile=tile)
+        backend.sync()
+        close(qk, pr[:, : 2 * C])
+        close(vt[:, :, :T], pr[:, 2 * C:].view(Bq, T, C).permute(0, 2, 1))
+    # conv (halo, M tail) on the full-row tiles
+    B, H, W, Cin, Cout = (2, 6, 5, 64, 320) if backend.is_emu else (3, 30, 44, 640, 320)
+    xc = rnd(B, Cin, H, W, seed=70)
+    wc = rnd(Cout, Cin, 3, 3, seed=71, scale=1 / math.sqrt(9 * Cin))
+    bc = torch.randn(Cout, generator=torch.Generator().manual_seed(72))
+    refc = F.conv2d(xc.float(), wc.float(), bc, padding=1).permute(0, 2, 3, 1)
+    pwc = ops.pack_conv3x3(wc.float(), bc, dev)
+    xh = xc.permute(0, 2, 3, 1).contiguous().to(dev)
+    for tile in (19, 21) if backend.is_emu else tiles:
+        out = torch.empty(B * H * W, Cout, dtype=BF16, device=dev)
+        ops.gemm(xh, pwc, out, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tile=tile)
+        backend.sync()
+        close(out.view(B, H, W, Cout), refc)
