@@ -55,7 +55,8 @@ struct GemmArgs {
     float* ws;
     int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
-    int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs
+    int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs, bit2 = per-workgroup
+                // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)
 };
 }  // namespace pcdm_gemm_detail
 
@@ -176,6 +177,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform -> LDS bases / branches in SGPRs
     const int wm = wave / WGN, wn = wave - wm * WGN;
+#ifndef PCDM_EMU
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+#define PCDM_STAMP(i) do { if (p.debug & 4) stamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PCDM_STAMP(i) ((void)0)
+#endif
+    PCDM_STAMP(0);
 
     // XCD-aware bijective remap of the linear workgroup id
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         for (int s = 0; s < D; ++s)
             if (s < nkt) issue_tile(s, s);
         int cur = 0, nxt = D % STAGES;  // stage of tile kt / of tile kt+D
+        PCDM_STAMP(1);
         for (int kt = 0; kt < nkt; ++kt) {
             // tile kt must have landed; up to D-1 younger tiles stay in flight across the barrier
             const int pending = (nkt - 1 - kt) < (D - 1) ? (nkt - 1 - kt) : (D - 1);
@@ -348,6 +357,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             else if (D >= 2 && pending == 1) wait_vm_then_barrier<AI + BI>();
             else wait_vm_then_barrier<0>();
             // every wave is past its reads of the stage tile kt+D goes to (it held tile kt-1)
+            if (kt == 0) PCDM_STAMP(2);
             if (kt + D < nkt && !(p.debug & 1)) issue_tile(kt + D, nxt);
             const u16* as = As + cur * BM * BK + (wm * WM + frow) * BK;
             const u16* bs = Bs + cur * BN * BK + (wn * WN + frow) * BK;
@@ -382,6 +392,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         }
     }
 
+    PCDM_STAMP(3);
     // ---- epilogue: lane holds, per (fn, fm, quad rg), channels n..n+3 of the pixel row (lane % F) of fragment row fm;
     // channel offset of quad rg inside its fragment: 8 rg + 4 (lane >> 5) for 32x32, 4 (lane >> 4) for 16x16
     const int half = lane >> LF;
@@ -473,6 +484,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                 if (geglu) break;   // (one pass holds the wave's 32 outputs h * act(gate))
             }
         }
+#ifndef PCDM_EMU
+        if ((p.debug & 4) && p.ws) {
+            PCDM_STAMP(4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the CU
+            PCDM_STAMP(5);
+            if (lane == 0) {
+                unsigned long long* o = (unsigned long long*)p.ws + ((int64_t)blockIdx.x * NW + wave) * 8;
+                for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+                o[6] = wg;
+            }
+        }
+#endif
         return;
     }
 #pragma unroll
