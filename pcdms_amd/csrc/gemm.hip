@@ -77,49 +77,96 @@ __device__ __forceinline__ float gate_act(float g, int act) { return act == PCDM
 __device__ __attribute__((aligned(32))) const unsigned int g_zero32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 // One pass of the LDS-staged epilogue: the wave's fp32 tile (32 rows x WCOLS channels, pitch EPW) is read back row-major, 16 B
-// (8 channels) per lane; out = act(acc + bias + rowvec) + residual as bf16.  All residual loads of the pass are issued first
-// (they come from HBM), then bias (constant per lane over the pass) and the per-row work.
-template <int WCOLS, int EPW>
-__device__ __forceinline__ void epi_store_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, bool glu) {
+// (8 channels) per lane; out = acc + bias + rowvec + residual as bf16 (activations take the generic path).  Written to be LEAN --
+// tools/gemm_anatomy.py (s_memtime stamps) showed the first version spending 15.7k-23.6k cycles per 96x80 wave tile, more than the
+// five K-tiles of a K = 320 main loop, on: a branch + s_waitcnt vmcnt(0) around every optional operand load, a three-way activation
+// switch per element, 64-bit address arithmetic and row predicates.  Here:
+//  * residual / row vector / output go through buffer descriptors sized to the tensors: rows >= M and masked lanes (offset bit 31)
+//    are dropped / read as zero by the bounds check (which applies to the per-lane offset, so the row term lives there);
+//  * HAS_RES / HAS_RV are compile-time (the caller branches once, wave-uniformly); every residual load of the pass is issued first;
+//  * 32-bit offsets, one add per store instruction.
+template <int WCOLS, int EPW, bool HAS_RES, bool HAS_RV>
+__device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, f32x4 b0, f32x4 b1,
+                                          BufRsrc rs_o, BufRsrc rs_r, BufRsrc rs_v) {
     constexpr int LPR = WCOLS / 8;                 // lanes per output row
     constexpr int RPI = 64 / LPR;                  // rows per store instruction (WCOLS = 48: 10, the last 4 lanes idle)
     constexpr int NIT = (32 + RPI - 1) / RPI;      // store instructions per pass
+    constexpr bool TAIL = NIT * RPI > 32;          // the last instruction covers rows beyond the pass (WCOLS = 48 only)
+    constexpr uint32_t kOOB = 0x80000000u;
     const int rl = lane / LPR, c8 = (lane - rl * LPR) * 8;
     const int n = ncol0 + c8;
     const bool lane_ok = rl < RPI && n < p.N;
-    const float* zf = (const float*)g_zero32;
-    const float* bp = (p.bias && !glu && lane_ok) ? p.bias + n : zf;
-    const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
-    const bool res_wrap = p.res_mod < p.M;
-    u16x8 rv[NIT];
-    bool ok[NIT];
+    const uint32_t vo0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldo + n) * 2) : kOOB;
+    const uint32_t so = (uint32_t)(RPI * (int)p.ldo * 2);
+    u32x4 rv[NIT];
+    if constexpr (HAS_RES) {
+        const uint32_t vr0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldr + n) * 2) : kOOB;
+        const uint32_t sr = (uint32_t)(RPI * (int)p.ldr * 2);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int r = it * RPI + rl, m = mrow0 + r;
-        ok[it] = lane_ok && r < 32 && m < p.M;
-        const u16* rp = (const u16*)zf;
-        if (p.residual && ok[it]) rp = p.residual + (int64_t)(res_wrap ? m % p.res_mod : m) * p.ldr + n;
-        rv[it] = *(const u16x8*)rp;
+        for (int it = 0; it < NIT; ++it) rv[it] = buf_load16(rs_r, (TAIL && it * RPI + rl >= 32) ? kOOB : vr0 + it * sr);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int r = it * RPI + rl, m = mrow0 + r;
-        const float* tp = zf;
-        if (p.rowvec && ok[it]) tp = p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n;
-        const f32x4 t0 = *(const f32x4*)tp, t1 = *(const f32x4*)(tp + 4);
-        const int rr = r < 32 ? r : 0;
+        const int r = it * RPI + rl;
+        const int rr = (TAIL && r >= 32) ? 0 : r;
         const f32x4 v0 = *(const f32x4*)(ep + rr * EPW + c8), v1 = *(const f32x4*)(ep + rr * EPW + c8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += b0[e] + t0[e]; v[e + 4] += b1[e] + t1[e]; }
-        if (p.act && !glu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+        f32x4 a0 = v0 + b0, a1 = v1 + b1;
+        if constexpr (HAS_RV) {   // rows of one instruction span at most two batch entries (rows_per_batch >= 32 on this path)
+            const int mb = mrow0 + it * RPI;                        // wave-uniform
+            const int b_lo = mb / p.rows_per_batch;
+            const int bidx = b_lo + ((mb + rl) >= (b_lo + 1) * p.rows_per_batch ? 1 : 0);
+            const uint32_t vv = lane_ok ? (uint32_t)((bidx * p.ldrv + n) * 4) : kOOB;
+            a0 += __builtin_bit_cast(f32x4, buf_load16(rs_v, vv));
+            a1 += __builtin_bit_cast(f32x4, buf_load16(rs_v, vv + 16));
         }
-        u16x8 o;
+        if constexpr (HAS_RES) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e] + bf2f(rv[it][e]));
-        if (ok[it]) *(u16x8*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
+            for (int e = 0; e < 4; ++e) {
+                a0[e] += __builtin_bit_cast(float, rv[it][e >> 1] << (e & 1 ? 0 : 16) & 0xffff0000u);
+                a1[e] += __builtin_bit_cast(float, rv[it][2 + (e >> 1)] << (e & 1 ? 0 : 16) & 0xffff0000u);
+            }
+        }
+        u32x4 o;
+        o[0] = pack2bf(a0[0], a0[1]);
+        o[1] = pack2bf(a0[2], a0[3]);
+        o[2] = pack2bf(a1[0], a1[1]);
+        o[3] = pack2bf(a1[2], a1[3]);
+        buf_store16(rs_o, (TAIL && r >= 32) ? kOOB : vo0 + it * so, o);
+    }
+}
+
+// wave-uniform dispatch on the operands present (one branch per pass instead of one per load)
+template <int WCOLS, int EPW>
+__device__ __forceinline__ void lean_pass_dyn(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, f32x4 b0, f32x4 b1,
+                                              BufRsrc rs_o, BufRsrc rs_r, BufRsrc rs_v, bool has_res, bool has_rv) {
+    if (!has_res && !has_rv) lean_pass<WCOLS, EPW, false, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
+    else if (has_res && !has_rv) lean_pass<WCOLS, EPW, true, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
+    else if (!has_res) lean_pass<WCOLS, EPW, false, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
+    else lean_pass<WCOLS, EPW, true, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
+}
+
+// V^T pass (PCDM_EPI_SPLIT_VT, columns >= vt_col0): the staged 32 tokens x WCOLS channels are read back COLUMN-wise -- a lane takes one
+// channel and 8 consecutive tokens -- and stored as 16 bytes along the token axis of out2[b, channel, token]: 64 contiguous bytes
+// per channel per pass instead of 2-byte scalar stores.  The 32 rows of a pass lie inside one batch entry (rows_per_batch % 32 == 0).
+template <int WCOLS, int EPW>
+__device__ __forceinline__ void vt_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, BufRsrc rs_vt) {
+    constexpr uint32_t kOOB = 0x80000000u;
+    const int b = mrow0 / p.rows_per_batch, tok0 = mrow0 - b * p.rows_per_batch;   // wave-uniform
+    const int cl = lane & 15, tg = lane >> 4;
+    const int cv = p.N - p.vt_col0;
+#pragma unroll
+    for (int ii = 0; ii < WCOLS / 16; ++ii) {
+        const int c = ii * 16 + cl, n = ncol0 + c;
+        const bool ok = n < p.N;
+        const float bias = *((p.bias && ok) ? p.bias + n : (const float*)g_zero32);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ep[(8 * tg + i) * EPW + c] + bias;
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        const uint32_t vo = ok ? (uint32_t)((((int64_t)b * cv + (n - p.vt_col0)) * p.ldo2 + tok0 + 8 * tg) * 2) : kOOB;
+        buf_store16(rs_vt, vo, o);
     }
 }
 
@@ -422,22 +469,46 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     // GEGLU: the packed weight rows alternate [32 h | 32 gate], so a 64-wide wave tile holds 32 outputs: h in its fragment columns
     // [0, FN/2), the matching gates in [FN/2, FN)
     constexpr bool GLU_OK = WN == 64;
-    if ((p.epilogue == PCDM_EPI_STORE || (p.epilogue == PCDM_EPI_GEGLU && GLU_OK)) && (p.N & 7) == 0 && (p.ldo & 7) == 0 &&
-        (!p.residual || (p.ldr & 7) == 0)) {
-        const bool geglu = p.epilogue == PCDM_EPI_GEGLU;
+    const bool geglu = p.epilogue == PCDM_EPI_GEGLU;
+    // q | k | v projections (PCDM_EPI_SPLIT_VT): tiles whose columns all lie below vt_col0 are plain stores
+    // (per WAVE: the waves of one workgroup may take different paths when vt_col0 is not a multiple of BN -- the barrier below is
+    //  therefore executed by every wave, before the paths part)
+    const bool qk_tile = p.epilogue == PCDM_EPI_SPLIT_VT && n0 + wn * WN + WN <= p.vt_col0;
+    const bool v_tile = p.epilogue == PCDM_EPI_SPLIT_VT && n0 + wn * WN >= p.vt_col0 && p.rows_per_batch % 32 == 0 && (p.ldo2 & 7) == 0 &&
+                        p.act == 0 && !p.residual && !p.rowvec && p.M % 32 == 0;
+    const bool lean = ((p.epilogue == PCDM_EPI_STORE && p.act == 0) || (geglu && GLU_OK) || qk_tile || v_tile) && (p.N & 7) == 0 &&
+                      (p.ldo & 7) == 0 && (!p.residual || ((p.ldr & 7) == 0 && p.res_mod >= p.M)) && (!p.rowvec || p.rows_per_batch >= 32);
+    __syncthreads();                                       // every wave is done with the operand stages
+    if (lean) {
         // staged in passes of 32 pixel rows x <= 64 channels (one 128-byte line of bf16 per row): RB fragment rows x CG fragment columns
         constexpr int RB = 32 / F;                         // fragment rows per pass
         constexpr int CGM = 64 / F;                        // fragment columns per full pass
         constexpr int CG = FN < CGM ? FN : CGM;
         constexpr int EPW = CG * F + 4;                    // fp32 row pitch (conflict-free ds_write_b128)
-        __syncthreads();                                   // every wave is done with the operand stages
+        const bool has_res = p.residual != nullptr && !geglu, has_rv = p.rowvec != nullptr && !geglu;
+        const int ncols_out = qk_tile ? p.vt_col0 : p.N;   // extent of a row of `out`
+        const BufRsrc rs_o = make_buf_rsrc(p.out, (uint32_t)((((int64_t)p.M - 1) * p.ldo + ncols_out) * 2));
+        const BufRsrc rs_r = make_buf_rsrc(has_res ? (const void*)p.residual : (const void*)p.out,
+                                           has_res ? (uint32_t)((((int64_t)p.M - 1) * p.ldr + p.N) * 2) : 0u);
+        const BufRsrc rs_v = make_buf_rsrc(has_rv ? (const void*)p.rowvec : (const void*)p.out,
+                                           has_rv ? (uint32_t)((((int64_t)(p.M - 1) / p.rows_per_batch) * p.ldrv + p.N) * 4) : 0u);
+        const BufRsrc rs_vt = make_buf_rsrc(v_tile ? (const void*)p.out2 : (const void*)p.out,
+                                            v_tile ? (uint32_t)((int64_t)(p.M / p.rows_per_batch) * (p.N - p.vt_col0) * p.ldo2 * 2) : 0u);
         float* ep = (float*)smem + wave * (32 * EPW);      // wave-private 32 x (CG*F) tile
 #pragma unroll
-        for (int jb = 0; jb < WM / 32; ++jb) {
+        for (int i0 = 0; i0 < FN; i0 += CG) {
+            const int ng = (FN - i0) < CG ? (FN - i0) : CG;   // fragment columns in this pass (the last pass may be narrower)
+            const int ncol0 = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN + i0 * F;
+            const int wc = geglu ? 32 : ng * F;               // columns of this pass (compile-time after unrolling, but for geglu)
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;         // bias of this lane's 8 channels: once per column group
+            if (!geglu && !v_tile) {                          // (GEGLU applies its biases before the gate, the V^T pass per channel)
+                const int c8_ = (lane % (wc / 8)) * 8;
+                const float* bp = (p.bias && ncol0 + c8_ < p.N) ? p.bias + ncol0 + c8_ : (const float*)g_zero32;
+                b0 = *(const f32x4*)bp;
+                b1 = *(const f32x4*)(bp + 4);
+            }
 #pragma unroll
-            for (int i0 = 0; i0 < FN; i0 += CG) {
-                const int ng = (FN - i0) < CG ? (FN - i0) : CG;   // fragment columns in this pass (the last pass may be narrower)
-                const int ncol0 = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN + i0 * F;
+            for (int jb = 0; jb < WM / 32; ++jb) {
                 // 1. quads -> LDS [row = pixel][col = channel]
                 if (geglu) {
                     if constexpr (GLU_OK) {
@@ -473,16 +544,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                         }
                 }
                 PCDM_WAVE_SYNC();
-                // 2. row-major read-back (same wave: LDS ops complete in order), fused epilogue, 16-byte stores
+                // 2. row-major read-back (same wave: LDS ops complete in order), 16-byte buffer stores
                 const int mrow0 = m0 + wm * WM + jb * 32;
-                if (geglu) epi_store_pass<32, EPW>(p, ep, lane, mrow0, ncol0, true);
-                else if (ng * F == 64) epi_store_pass<64, EPW>(p, ep, lane, mrow0, ncol0, false);
-                else if (ng * F == 32) epi_store_pass<32, EPW>(p, ep, lane, mrow0, ncol0, false);
-                else if (ng * F == 16) epi_store_pass<16, EPW>(p, ep, lane, mrow0, ncol0, false);
-                else epi_store_pass<48, EPW>(p, ep, lane, mrow0, ncol0, false);
+                if (geglu) lean_pass<32, EPW, false, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
+                else if (v_tile) {
+                    if (mrow0 < p.M) {
+                        if (ng * F == 64) vt_pass<64, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                        else if (ng * F == 32) vt_pass<32, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                        else if (ng * F == 16) vt_pass<16, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                        else vt_pass<48, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                    }
+                } else if (ng * F == 64) lean_pass_dyn<64, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
+                else if (ng * F == 32) lean_pass_dyn<32, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
+                else if (ng * F == 16) lean_pass_dyn<16, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
+                else lean_pass_dyn<48, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
                 PCDM_WAVE_SYNC();   // this pass's reads precede the next pass's writes
-                if (geglu) break;   // (one pass holds the wave's 32 outputs h * act(gate))
             }
+            if (geglu) break;   // (one column pass holds the wave's 32 outputs h * act(gate))
         }
 #ifndef PCDM_EMU
         if ((p.debug & 4) && p.ws) {
@@ -699,6 +777,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if ((int64_t)p->Npad * (p->ldw > 0 ? p->ldw : p->K) * 2 >= lim) return -2;
     if (p->conv ? ((int64_t)p->B * p->Hi * p->Wi * p->cin * 2 + ((int64_t)p->Wi + 1) * p->cin * 2 >= lim)
                 : ((int64_t)p->M * p->lda * 2 >= lim || (p->a2 && (int64_t)p->M * p->lda2 * 2 >= lim))) return -2;
+    if ((int64_t)p->M * (p->ldo > 0 ? p->ldo : p->N) * 4 >= lim || (p->residual && (int64_t)p->M * (p->ldr > 0 ? p->ldr : p->N) * 2 >= lim))
+        return -2;   // (32-bit offsets in the epilogue's buffer stores / loads)
     GemmArgs a;
     a.a = (const u16*)p->a;
     a.a2 = (const u16*)p->a2;

@@ -36,6 +36,18 @@ __device__ __forceinline__ u16 f2bf(float f) {
     return (u16)(u >> 16);
 }
 
+// two fp32 -> one dword of two bf16 (lo in bits 0..15): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+#ifndef PCDM_EMU
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+#else
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#endif
+}
+
 // ---- launch / dynamic LDS ------------------------------------------------------------------
 #ifdef PCDM_EMU
 #define PCDM_DYN_SMEM(name) char* name = emu::dyn_smem
@@ -73,20 +85,38 @@ __device__ __forceinline__ void glds_wait() {
 // address = base + voff (per lane, VGPR) + soff (wave-uniform, SGPR); lanes whose voff has bit 31 set are out
 // of range: the hardware bounds check makes them deliver ZEROS (no branch, no separate zero source).
 #ifdef PCDM_EMU
-struct BufRsrc { const char* base; };
-__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p) { return BufRsrc{(const char*)p}; }
+struct BufRsrc { const char* base; uint32_t size; };
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, uint32_t bytes = 0x7fffffffu) { return BufRsrc{(const char*)p, bytes}; }
 __device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
     char* d = (char*)lds_wave_base + 16 * emu::lane_id();
-    if (voff & 0x80000000u) memset(d, 0, 16);
+    if (voff >= r.size) memset(d, 0, 16);
     else memcpy(d, r.base + voff + soff, 16);
+}
+// 16-byte register load / store through a descriptor: voff >= size (the bounds check is on the per-lane offset) reads zeros /
+// drops the store -- rows beyond the tensor and masked lanes (voff bit 31) need no predicate and no branch
+__device__ __forceinline__ u32x4 buf_load16(BufRsrc r, uint32_t voff) {
+    u32x4 v = {0, 0, 0, 0};
+    if (voff < r.size && voff + 16 <= r.size) memcpy(&v, r.base + voff, 16);
+    return v;
+}
+__device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
+    if (voff < r.size && voff + 16 <= r.size) memcpy(const_cast<char*>(r.base) + voff, &v, 16);
 }
 #else
 struct BufRsrc { __amdgpu_buffer_rsrc_t r; };
-__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p) {
-    return BufRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)};
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, uint32_t bytes = 0x7fffffffu) {
+    return BufRsrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000)};
 }
 __device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+// 16-byte register load / store through a descriptor: voff >= num_records (the bounds check is on the per-lane offset) reads zeros /
+// drops the store -- rows beyond the tensor and masked lanes (voff bit 31) need no predicate and no branch
+__device__ __forceinline__ u32x4 buf_load16(BufRsrc r, uint32_t voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r.r, voff, 0, 0);
 }
 #endif
 

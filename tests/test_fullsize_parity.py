@@ -32,10 +32,11 @@ from tests.test_schedulers import SD21
 from tests.test_unet import _kwargs
 
 FIXTURE = Path(__file__).resolve().parent / "golden" / "fullsize_config2.npz"
-FWD_TOL = 1.5e-2      # one forward, rel-L2 of the guided eps (round 1 measured 0.78e-2 on a builder-side run)
-TRAJ_TOL = 3e-2       # latents along / at the end of the 50-step trajectory
-PIX_TOL = 3.0         # mean absolute difference in uint8 levels over a canvas
-PIX_MEAN_TOL = 1.5    # |mean(canvas) - mean(oracle canvas)| in uint8 levels
+FWD_TOL = 2.5e-2      # one forward, rel-L2 of the guided eps: the suite's forward tolerance (tests/test_unet.py); measured 0.95e-2 .. 1.67e-2
+TRAJ_TOL = 5e-3       # latents along / at the end of the 50-step trajectory (measured 0.7e-3 .. 0.8e-3: the DDIM update is dominated by
+                      # its deterministic rescale of the latents, which both sides compute in fp32)
+PIX_TOL = 1.0         # mean absolute difference in uint8 levels over a canvas (measured 0.34; bf16 VAE alone 0.34)
+PIX_MEAN_TOL = 0.25   # |mean(canvas) - mean(oracle canvas)| in uint8 levels (measured <= 0.022)
 
 
 def _rel(a, b):

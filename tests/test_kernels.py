@@ -181,6 +181,26 @@ def test_gemm_split_vt_and_nchw(backend):
     close(qk, ref[:, : 2 * Cc])
     close(vt[:, :, :L], ref[:, 2 * Cc:].view(B, L, Cc).permute(0, 2, 1))
     assert (vt[:, :, L:] == 0).all()
+    # token counts that are multiples of 32 take the staged epilogue: q | k as 16-byte row stores, V^T as 16-byte stores along the token
+    # axis (transposed read-back from LDS); several tile shapes incl. one whose N tiles straddle vt_col0 (256-wide tiles, vt_col0 = 128:
+    # the waves of one workgroup take different paths) and a bias
+    for (B2, L2, C2, tiles) in ([(2, 64, 64, (2, 3, 4)), (3, 32, 128, (4, 17, 13))] if backend.is_emu else
+                                [(8, 1408, 640, (0, 3, 4, 13, 17, 18, 19, 21)), (2, 352, 1280, (17, 21, 26)), (8, 5632, 320, (21, 19, 13))]):
+        a2 = rnd(B2 * L2, K, seed=44)
+        w2 = rnd(3 * C2, K, seed=45, scale=1 / math.sqrt(K))
+        b2 = torch.randn(3 * C2, generator=torch.Generator().manual_seed(46))
+        pw2 = ops.pack_linear(w2.float(), b2, dev)
+        ref2 = a2.float() @ w2.float().t() + b2
+        for tile in tiles:
+            if tile and pw2.Npad % ops.TILE_SHAPES[tile][1]:
+                continue
+            qk2 = torch.zeros(B2 * L2, 2 * C2, dtype=BF16, device=dev)
+            vt2 = torch.zeros(B2, C2, L2 + 8, dtype=BF16, device=dev)
+            ops.gemm(a2.to(dev), pw2, qk2, rows_per_batch=L2, epilogue=ops.EPI_SPLIT_VT, out2=vt2, vt_col0=2 * C2, tile=tile)
+            backend.sync()
+            close(qk2, ref2[:, : 2 * C2])
+            close(vt2[:, :, :L2], ref2[:, 2 * C2:].view(B2, L2, C2).permute(0, 2, 1))
+            assert (vt2[:, :, L2:] == 0).all(), tile
     # NCHW fp32 output with N = 4 (conv_out shape class)
     w4 = rnd(4, K, seed=42, scale=1 / math.sqrt(K))
     b4 = torch.randn(4, generator=torch.Generator().manual_seed(43))
