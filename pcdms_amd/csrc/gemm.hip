@@ -85,26 +85,42 @@ __device__ __attribute__((aligned(32))) const unsigned int g_zero32[8] = {0, 0, 
 //    are dropped / read as zero by the bounds check (which applies to the per-lane offset, so the row term lives there);
 //  * HAS_RES / HAS_RV are compile-time (the caller branches once, wave-uniformly); every residual load of the pass is issued first;
 //  * 32-bit offsets, one add per store instruction.
-template <int WCOLS, int EPW, bool HAS_RES, bool HAS_RV>
+// geometry of a pass: lane -> (row within the store instruction, first of its 8 channels)
+template <int WCOLS>
+struct PassGeom {
+    static constexpr int LPR = WCOLS / 8;                 // lanes per output row
+    static constexpr int RPI = 64 / LPR;                  // rows per store instruction (WCOLS = 48: 10, the last 4 lanes idle)
+    static constexpr int NIT = (32 + RPI - 1) / RPI;      // store instructions per pass (<= 4)
+    static constexpr bool TAIL = NIT * RPI > 32;          // the last instruction covers rows beyond the pass (WCOLS = 48 only)
+};
+
+// residual rows of one pass -> registers (issued two passes ahead of their use: they come from HBM; a descriptor of size 0 --
+// no residual -- returns zeros without touching memory, so the loads are unconditional)
+template <int WCOLS>
+__device__ __forceinline__ void lean_res_load(const GemmArgs& p, int lane, int mrow0, int ncol0, BufRsrc rs_r, u32x4 (&rv)[4]) {
+    typedef PassGeom<WCOLS> G;
+    constexpr uint32_t kOOB = 0x80000000u;
+    const int rl = lane / G::LPR, c8 = (lane - rl * G::LPR) * 8;
+    const int n = ncol0 + c8;
+    const bool lane_ok = rl < G::RPI && n < p.N;
+    const uint32_t vr0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldr + n) * 2) : kOOB;
+    const uint32_t sr = (uint32_t)(G::RPI * (int)p.ldr * 2);
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) rv[it] = buf_load16(rs_r, (G::TAIL && it * G::RPI + rl >= 32) ? kOOB : vr0 + it * sr);
+}
+
+template <int WCOLS, int EPW, bool HAS_RV>
 __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, f32x4 b0, f32x4 b1,
-                                          BufRsrc rs_o, BufRsrc rs_r, BufRsrc rs_v) {
-    constexpr int LPR = WCOLS / 8;                 // lanes per output row
-    constexpr int RPI = 64 / LPR;                  // rows per store instruction (WCOLS = 48: 10, the last 4 lanes idle)
-    constexpr int NIT = (32 + RPI - 1) / RPI;      // store instructions per pass
-    constexpr bool TAIL = NIT * RPI > 32;          // the last instruction covers rows beyond the pass (WCOLS = 48 only)
+                                          BufRsrc rs_o, BufRsrc rs_v, const u32x4 (&rv)[4]) {
+    typedef PassGeom<WCOLS> G;
+    constexpr int LPR = G::LPR, RPI = G::RPI, NIT = G::NIT;
+    constexpr bool TAIL = G::TAIL;
     constexpr uint32_t kOOB = 0x80000000u;
     const int rl = lane / LPR, c8 = (lane - rl * LPR) * 8;
     const int n = ncol0 + c8;
     const bool lane_ok = rl < RPI && n < p.N;
     const uint32_t vo0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldo + n) * 2) : kOOB;
     const uint32_t so = (uint32_t)(RPI * (int)p.ldo * 2);
-    u32x4 rv[NIT];
-    if constexpr (HAS_RES) {
-        const uint32_t vr0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldr + n) * 2) : kOOB;
-        const uint32_t sr = (uint32_t)(RPI * (int)p.ldr * 2);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) rv[it] = buf_load16(rs_r, (TAIL && it * RPI + rl >= 32) ? kOOB : vr0 + it * sr);
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int r = it * RPI + rl;
@@ -119,12 +135,10 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
             a0 += __builtin_bit_cast(f32x4, buf_load16(rs_v, vv));
             a1 += __builtin_bit_cast(f32x4, buf_load16(rs_v, vv + 16));
         }
-        if constexpr (HAS_RES) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a0[e] += __builtin_bit_cast(float, rv[it][e >> 1] << (e & 1 ? 0 : 16) & 0xffff0000u);
-                a1[e] += __builtin_bit_cast(float, rv[it][2 + (e >> 1)] << (e & 1 ? 0 : 16) & 0xffff0000u);
-            }
+        for (int e = 0; e < 4; ++e) {   // residual (zeros when there is none)
+            a0[e] += __builtin_bit_cast(float, rv[it][e >> 1] << (e & 1 ? 0 : 16) & 0xffff0000u);
+            a1[e] += __builtin_bit_cast(float, rv[it][2 + (e >> 1)] << (e & 1 ? 0 : 16) & 0xffff0000u);
         }
         u32x4 o;
         o[0] = pack2bf(a0[0], a0[1]);
@@ -133,16 +147,6 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
         o[3] = pack2bf(a1[2], a1[3]);
         buf_store16(rs_o, (TAIL && r >= 32) ? kOOB : vo0 + it * so, o);
     }
-}
-
-// wave-uniform dispatch on the operands present (one branch per pass instead of one per load)
-template <int WCOLS, int EPW>
-__device__ __forceinline__ void lean_pass_dyn(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, f32x4 b0, f32x4 b1,
-                                              BufRsrc rs_o, BufRsrc rs_r, BufRsrc rs_v, bool has_res, bool has_rv) {
-    if (!has_res && !has_rv) lean_pass<WCOLS, EPW, false, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
-    else if (has_res && !has_rv) lean_pass<WCOLS, EPW, true, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
-    else if (!has_res) lean_pass<WCOLS, EPW, false, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
-    else lean_pass<WCOLS, EPW, true, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
 }
 
 // V^T pass (PCDM_EPI_SPLIT_VT, columns >= vt_col0): the staged 32 tokens x WCOLS channels are read back COLUMN-wise -- a lane takes one
@@ -495,72 +499,89 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         const BufRsrc rs_vt = make_buf_rsrc(v_tile ? (const void*)p.out2 : (const void*)p.out,
                                             v_tile ? (uint32_t)((int64_t)(p.M / p.rows_per_batch) * (p.N - p.vt_col0) * p.ldo2 * 2) : 0u);
         float* ep = (float*)smem + wave * (32 * EPW);      // wave-private 32 x (CG*F) tile
+        constexpr int NCG = (FN + CG - 1) / CG, NJB = WM / 32;
+        // pass q = (column group q / NJB, row block q % NJB); GEGLU needs WN == 64, i.e. a single column group
+        u32x4 rv[NCG * NJB][4];                            // residual rows, loaded two passes ahead (static indices: registers)
+        auto pass_cols = [&](int q) { const int i0 = (q / NJB) * CG; return geglu ? 32 : ((FN - i0) < CG ? (FN - i0) : CG) * F; };
+        auto pass_ncol0 = [&](int q) { return geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN + (q / NJB) * CG * F; };
+        auto issue_res = [&](int q) {
+            const int mrow0 = m0 + wm * WM + (q % NJB) * 32, wc = pass_cols(q), nc = pass_ncol0(q);
+            if (wc == 64) lean_res_load<64>(p, lane, mrow0, nc, rs_r, rv[q]);
+            else if (wc == 32) lean_res_load<32>(p, lane, mrow0, nc, rs_r, rv[q]);
+            else if (wc == 16) lean_res_load<16>(p, lane, mrow0, nc, rs_r, rv[q]);
+            else lean_res_load<48>(p, lane, mrow0, nc, rs_r, rv[q]);
+        };
+        issue_res(0);
+        if (NCG * NJB > 1) issue_res(1);
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;          // bias of this lane's 8 channels: reloaded once per column group
 #pragma unroll
-        for (int i0 = 0; i0 < FN; i0 += CG) {
-            const int ng = (FN - i0) < CG ? (FN - i0) : CG;   // fragment columns in this pass (the last pass may be narrower)
-            const int ncol0 = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN + i0 * F;
-            const int wc = geglu ? 32 : ng * F;               // columns of this pass (compile-time after unrolling, but for geglu)
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;         // bias of this lane's 8 channels: once per column group
-            if (!geglu && !v_tile) {                          // (GEGLU applies its biases before the gate, the V^T pass per channel)
+        for (int q = 0; q < NCG * NJB; ++q) {
+            const int i0 = (q / NJB) * CG, jb = q % NJB;
+            const int ng = (FN - i0) < CG ? (FN - i0) : CG;   // fragment columns in this pass (the last column group may be narrower)
+            const int ncol0 = pass_ncol0(q), wc = pass_cols(q);
+            if (jb == 0 && !geglu && !v_tile) {               // (GEGLU applies its biases before the gate, the V^T pass per channel)
                 const int c8_ = (lane % (wc / 8)) * 8;
                 const float* bp = (p.bias && ncol0 + c8_ < p.N) ? p.bias + ncol0 + c8_ : (const float*)g_zero32;
                 b0 = *(const f32x4*)bp;
                 b1 = *(const f32x4*)(bp + 4);
             }
-#pragma unroll
-            for (int jb = 0; jb < WM / 32; ++jb) {
-                // 1. quads -> LDS [row = pixel][col = channel]
-                if (geglu) {
-                    if constexpr (GLU_OK) {
-#pragma unroll
-                        for (int jj = 0; jj < RB; ++jj)
-#pragma unroll
-                            for (int i = 0; i < FN / 2; ++i)
-#pragma unroll
-                                for (int rg = 0; rg < NQ; ++rg) {
-                                    const int nl = i * F + QS * rg + 4 * half;   // 0..31 within the wave's 32 outputs
-                                    const f32x4 bh = *(const f32x4*)(p.bias + n0 + wn * WN + nl);
-                                    const f32x4 bg = *(const f32x4*)(p.bias + n0 + wn * WN + nl + 32);
-                                    const acc_t& ah = acc[i][jb * RB + jj];
-                                    const acc_t& ag = acc[i + FN / 2][jb * RB + jj];
-                                    f32x4 v;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * gate_act(ag[4 * rg + e] + bg[e], p.act);
-                                    *(f32x4*)(ep + (jj * F + prow) * EPW + nl) = v;
-                                }
-                    }
-                } else {
+            if (q + 2 < NCG * NJB) issue_res(q + 2);
+            // 1. quads -> LDS [row = pixel][col = channel]
+            if (geglu) {
+                if constexpr (GLU_OK) {
 #pragma unroll
                     for (int jj = 0; jj < RB; ++jj)
 #pragma unroll
-                        for (int i = 0; i < CG; ++i) {
-                            if (i0 + i >= FN) break;
+                        for (int i = 0; i < FN / 2; ++i)
 #pragma unroll
                             for (int rg = 0; rg < NQ; ++rg) {
-                                const acc_t& a_ = acc[i0 + i < FN ? i0 + i : 0][jb * RB + jj];
-                                const f32x4 v = {a_[4 * rg], a_[4 * rg + 1], a_[4 * rg + 2], a_[4 * rg + 3]};
-                                *(f32x4*)(ep + (jj * F + prow) * EPW + i * F + QS * rg + 4 * half) = v;
+                                const int nl = i * F + QS * rg + 4 * half;   // 0..31 within the wave's 32 outputs
+                                const f32x4 bh = *(const f32x4*)(p.bias + n0 + wn * WN + nl);
+                                const f32x4 bg = *(const f32x4*)(p.bias + n0 + wn * WN + nl + 32);
+                                const acc_t& ah = acc[i][jb * RB + jj];
+                                const acc_t& ag = acc[i + FN / 2][jb * RB + jj];
+                                f32x4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * gate_act(ag[4 * rg + e] + bg[e], p.act);
+                                *(f32x4*)(ep + (jj * F + prow) * EPW + nl) = v;
                             }
-                        }
                 }
-                PCDM_WAVE_SYNC();
-                // 2. row-major read-back (same wave: LDS ops complete in order), 16-byte buffer stores
-                const int mrow0 = m0 + wm * WM + jb * 32;
-                if (geglu) lean_pass<32, EPW, false, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v);
-                else if (v_tile) {
-                    if (mrow0 < p.M) {
-                        if (ng * F == 64) vt_pass<64, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
-                        else if (ng * F == 32) vt_pass<32, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
-                        else if (ng * F == 16) vt_pass<16, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
-                        else vt_pass<48, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < RB; ++jj)
+#pragma unroll
+                    for (int i = 0; i < CG; ++i) {
+                        if (i0 + i >= FN) break;
+#pragma unroll
+                        for (int rg = 0; rg < NQ; ++rg) {
+                            const acc_t& a_ = acc[i0 + i < FN ? i0 + i : 0][jb * RB + jj];
+                            const f32x4 v = {a_[4 * rg], a_[4 * rg + 1], a_[4 * rg + 2], a_[4 * rg + 3]};
+                            *(f32x4*)(ep + (jj * F + prow) * EPW + i * F + QS * rg + 4 * half) = v;
+                        }
                     }
-                } else if (ng * F == 64) lean_pass_dyn<64, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
-                else if (ng * F == 32) lean_pass_dyn<32, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
-                else if (ng * F == 16) lean_pass_dyn<16, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
-                else lean_pass_dyn<48, EPW>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_r, rs_v, has_res, has_rv);
-                PCDM_WAVE_SYNC();   // this pass's reads precede the next pass's writes
             }
-            if (geglu) break;   // (one column pass holds the wave's 32 outputs h * act(gate))
+            PCDM_WAVE_SYNC();
+            // 2. row-major read-back (same wave: LDS ops complete in order), 16-byte buffer stores
+            const int mrow0 = m0 + wm * WM + jb * 32;
+            if (v_tile) {
+                if (mrow0 < p.M) {
+                    if (ng * F == 64) vt_pass<64, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                    else if (ng * F == 32) vt_pass<32, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                    else if (ng * F == 16) vt_pass<16, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                    else vt_pass<48, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                }
+            } else if (has_rv) {
+                if (wc == 64) lean_pass<64, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                else if (wc == 32) lean_pass<32, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                else if (wc == 16) lean_pass<16, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                else lean_pass<48, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+            } else {
+                if (wc == 64) lean_pass<64, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                else if (wc == 32) lean_pass<32, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                else if (wc == 16) lean_pass<16, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                else lean_pass<48, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+            }
+            PCDM_WAVE_SYNC();   // this pass's reads precede the next pass's writes
         }
 #ifndef PCDM_EMU
         if ((p.debug & 4) && p.ws) {
@@ -750,19 +771,17 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         // 64..128 x 160.  With BN = 64 the A tile is re-fetched by 5 N tiles and the loop sits on the L2 -> LDS rate
         // (~19 TB/s measured) and the LDS read rate (1.5 ds_read_b128 per MFMA); a 64x160 wave tile needs 0.7 reads per MFMA
         // and 2.8x fewer staged bytes per FLOP.
-        case 19: return launch_gemm<256, 320, 4, 2, 2, CONV>(a, st);   // 8 waves (64x160 each), 144 KiB, 1 block / CU
-        case 20: return launch_gemm<128, 320, 2, 2, 2, CONV>(a, st);   // 4 waves (64x160 each), 112 KiB, 1 block / CU
+        // (first built with 32x32 fragments -- 256x320 / 8 waves of 64x160, 128x320, 128x160 -- which ran the loop at ~1.28 PF/s
+        //  but left 80 of the 256 CUs idle at M = 45056 (176 tiles); superseded by the 16x16x32-fragment tiles below)
         // (192x320 / 256x320 with FOUR waves of 96x160 / 128x160 32x32 fragments -- one wave per SIMD, AGPR accumulators -- were tried
         //  and dropped: hipcc 7.2 crashes in 'AMDGPU Rewrite AGPR-Copy-MFMA' under -amdgpu-mfma-vgpr-form=1 and spills ~2 KiB per
         //  lane without it)
         // 16x16x32 fragments: wave tile 96x80.  192-row tiles: M = 45056 -> 235 workgroups (N = 320), M = 11264 -> 59 x 2 (N = 640),
         // M = 2816 -> 15 x 4 (N = 1280); 96-row tiles: M = 11264 -> 118 x 2 = 236 -- all within 8 % of the 256 CUs.
         case 21: return launch_gemm<192, 320, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves, 128 KiB, 1 block / CU
-        case 22: return launch_gemm<96, 320, 1, 4, 2, CONV, false, 16>(a, st);    // 4 waves, 104 KiB, 1 block / CU
-        case 25: return launch_gemm<96, 320, 1, 4, 3, CONV, false, 16>(a, st);    // 4 waves, 156 KiB, 1 block / CU, two tiles in flight
+        // (measured and dropped, never selected by the tuner: 128x320 / 4 waves; 96x320 / 4 waves of 96x80 with two or three stages;
+        //  128x160 / 2 waves with three stages)
         case 26: return launch_gemm<192, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96x64 each: GEGLU-capable), 112 KiB
-        case 23: return launch_gemm<128, 160, 2, 1, 2, CONV>(a, st);   // 2 waves (64x160 each), 72 KiB, 2 blocks / CU
-        case 24: return launch_gemm<128, 160, 2, 1, 3, CONV>(a, st);   // 2 waves, 108 KiB, 1 block / CU, two tiles in flight
         default: return -1;
     }
 }

@@ -232,7 +232,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),
                15: (128, 64), 16: (512, 64), 17: (256, 256), 18: (128, 128),
-               19: (256, 320), 20: (128, 320), 21: (192, 320), 22: (96, 320), 23: (128, 160), 24: (128, 160), 25: (96, 320), 26: (192, 256)}
+               21: (192, 320), 26: (192, 256)}
 _TUNED: dict = {}
 _WS: dict = {}
 
