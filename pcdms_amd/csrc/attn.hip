@@ -17,6 +17,14 @@
 //    (PCDM_EPI_SPLIT_VT), so the A operand of the PV MFMA is a plain ds_read_b128 -- no transpose
 //    anywhere in this kernel.
 //  * LDS rows are unpadded and XOR-swizzled (conflict-free ds_read_b128, see gemm.hip).
+//  * The softmax is VALU-bound at head_dim 64 (one exp per 256 FLOP), so the VALU work per score is cut to the exp itself:
+//    Q is pre-multiplied by scale * log2(e) (once per workgroup), and the running reference m of each query is subtracted INSIDE the
+//    QK^T contraction by one extra MFMA per key fragment (A = ones, B = a fragment holding bf16(-m) in its k = 0 slot), so that
+//    P = exp2(S') with S' straight out of the accumulator -- no per-score fma.  m is LAZY (cdna_hip_programming.md T13): it moves
+//    only when a tile's maximum exceeds it by more than `thr` (log2 units; the first tile always sets it), and only then are the
+//    scores of that tile, O and the row sum rescaled.  m is kept bf16-exact, so the value the MFMA subtracts is exactly the one the
+//    rescale factors are computed from; any reference would do for the mathematics (P, the row sum and O all carry the same
+//    2^-m), thr only bounds P <= 2^thr.  thr = 0 reproduces the eager online softmax.
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 
@@ -27,11 +35,11 @@ constexpr int KB = 64;     // keys per tile
 constexpr int QPW = 32;    // queries per wave
 constexpr int QPB = 128;   // queries per workgroup
 
-__global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
                                                          const u16* __restrict__ k, int64_t ldk,
                                                          const u16* __restrict__ vt, int64_t ldvt,
                                                          u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
-                                                         float c /* scale * log2(e) */) {
+                                                         float c /* scale * log2(e) */, float thr /* lazy-rescale threshold, log2 units */) {
     // K tile [64 keys][64 d] and V^T tile [64 d][64 keys], 2 stages each, unpadded 128-byte rows whose 16-byte
     // chunks are XOR-swizzled by (row>>1)&7 (applied on the DMA source offset and on the fragment reads, exactly
     // as in gemm.hip): conflict-free ds_read_b128, filled by buffer_load ... lds with no VGPR round trip.
@@ -50,7 +58,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
     const u16* qp = q + ((int64_t)b * Lq + qrow) * ldq + h * 64 + hh * 8;
     u16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u16x8*)(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+        const u16x8 raw = *(const u16x8*)(qp + ks * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = f2bf(bf2f(raw[e]) * c);   // scores come out of the MFMA in log2 units
+    }
 
     // LDS-DMA staging: wave w, instruction j fills rows (2w+j)*8 .. +7 of the K tile and of the V^T tile
     constexpr uint32_t kOOB = 0x80000000u;
@@ -81,7 +93,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
     f32x16 oacc[2], lacc;      // lacc: row sums on the matrix pipe (every register of a lane holds sum_k P[q, k])
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = lacc[r] = 0.f;
-    float m_run = -1e30f;
+    float m_ref = 0.f;         // per query: the (bf16-exact) reference subtracted inside the contraction
+    u16x8 qm = {0, 0, 0, 0, 0, 0, 0, 0};   // B fragment of the extra k-step: element k = 0 (lane half 0, e = 0) holds bf16(-m_ref)
     const u16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
 
     const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);  // K row permutation
@@ -113,6 +126,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(kfr[ks][kf], qf[ks], s[kf]);
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(ones, qm, s[kf]);   // S' = S - m_ref
         // the V^T fragments of this tile are requested now, so that their LDS latency hides behind the softmax VALU work
         u16x8 vfr[4][2];
 #pragma unroll
@@ -129,29 +144,36 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
                 for (int r = 0; r < 16; ++r)
                     if (key0 + 32 * kf + 16 * (r >> 3) + 8 * hh + (r & 7) >= Lk) s[kf][r] = -1e30f;
         }
-        // ---- online softmax (fp32): max over this lane's 32 keys + the partner lane's 32
+        // ---- lazy online softmax (fp32): max over this lane's 32 keys + the partner lane's 32, relative to m_ref
         float mx = s[0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        const bool bump = kb == 0 || mx > thr;                 // this query's reference must move (always at the first tile)
+        if (wave_any(bump)) {                                  // wave-uniform: rare after the first tiles
+            const float m_new = bump ? bf2f(f2bf(m_ref + mx)) : m_ref;   // bf16-exact
+            const float delta = m_new - m_ref;                 // exact: 0 for the queries that stay
+            const float alpha = fast_exp2(-delta);
+            m_ref = m_new;
+            qm[0] = hh == 0 ? f2bf(-m_new) : (u16)0;
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kf][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                oacc[0][r] *= alpha;
+                oacc[1][r] *= alpha;
+            }
+            lacc[0] *= alpha;   // only register 0 is ever read back: l = l*alpha + sum_k P (added by the MFMA below)
+        }
         u16x8 pf[4];
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                pf[2 * kf + (r >> 3)][r & 7] = f2bf(fast_exp2(fmaf(s[kf][r], c, -mc)));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            oacc[0][r] *= alpha;
-            oacc[1][r] *= alpha;
-        }
-        lacc[0] *= alpha;   // only register 0 is ever read back: l = l*alpha + sum_k P (added by the MFMA below)
+            for (int r = 0; r < 16; ++r) pf[2 * kf + (r >> 3)][r & 7] = f2bf(fast_exp2(s[kf][r]));
         // ---- O^T += V^T P^T ; row sums += 1^T P^T (the softmax denominator is accumulated by the matrix pipe,
         //      which has slack here, instead of 32 VALU adds per tile -- the kernel is VALU-bound at d = 64)
 #pragma unroll
@@ -184,14 +206,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const u16* __restrict__
 }
 }  // namespace
 
-extern "C" int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
-                               void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, pcdm_stream_t s) {
+extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                                   void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s) {
     if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
     if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < Lk) return -1;
+    if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
     PCDM_LAUNCH(flash_attn_kernel, grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
-                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f);
+                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2);
     PCDM_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                               void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, pcdm_stream_t s) {
+    return pcdm_flash_attn_thr(q, ldq, k, ldk, vt, ldvt, o, ldo, B, H, Lq, Lk, scale, PCDM_ATTN_DEFAULT_THR, s);
 }

@@ -257,6 +257,15 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 }
 
+// any lane's predicate true? (wave-uniform result: s_cmp on the ballot mask)
+__device__ __forceinline__ bool wave_any(bool v) {
+#ifdef PCDM_EMU
+    return wave_max(v ? 1.f : 0.f) > 0.f;
+#else
+    return __builtin_amdgcn_ballot_w64(v) != 0;
+#endif
+}
+
 #define PCDM_CHECK_LAUNCH()                          \
     do {                                             \
         hipError_t e_ = hipGetLastError();           \

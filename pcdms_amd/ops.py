@@ -337,7 +337,7 @@ if os.environ.get("PCDM_NO_TUNING_TABLE") != "1":   # (the online autotuner alon
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,
-               Lk: int, scale: Optional[float] = None) -> torch.Tensor:
+               Lk: int, scale: Optional[float] = None, thr: Optional[float] = None) -> torch.Tensor:
     """q [B*Lq, ldq], k [B*Lk, ldk] (views allowed: row stride = .stride(0)), vt [B, H*64, ldvt], out [B*Lq, ldo]."""
     for t in (q, k, vt, out):
         assert t.dtype == BF16
@@ -347,8 +347,12 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
     if log:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _lib.lib().pcdm_flash_attn(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out),
-                                   out.stride(0), B, H, Lq, Lk, scale, _stream(q))
+    if thr is None:
+        rc = _lib.lib().pcdm_flash_attn(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out),
+                                       out.stride(0), B, H, Lq, Lk, scale, _stream(q))
+    else:   # explicit lazy-rescale threshold (log2 units; 0 = eager online softmax)
+        rc = _lib.lib().pcdm_flash_attn_thr(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out),
+                                           out.stride(0), B, H, Lq, Lk, scale, float(thr), _stream(q))
     _chk(rc, "pcdm_flash_attn")
     if log:
         e1.record()

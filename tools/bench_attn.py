@@ -28,4 +28,15 @@ for (H, Lq, Lk) in [(5, 5632, 5632), (10, 1408, 1408), (20, 352, 352), (5, 5632,
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"attn B{B} H{H} Lq{Lq} Lk{Lk}: {us:8.1f} us  {4.0 * B * H * Lq * Lk * 64 / us / 1e6:7.1f} TF/s", flush=True)
+    res = [f"{us:8.1f} us {4.0 * B * H * Lq * Lk * 64 / us / 1e6:7.1f} TF/s (default thr)"]
+    for thr in (0.0, 2.0, 8.0):   # lazy-rescale threshold sweep (0 = eager online softmax)
+        for _ in range(2):
+            ops.flash_attn(q, k, vt, out, B, H, Lq, Lk, thr=thr)
+        e0.record()
+        for _ in range(20):
+            ops.flash_attn(q, k, vt, out, B, H, Lq, Lk, thr=thr)
+        e1.record()
+        e1.synchronize()
+        u2 = e0.elapsed_time(e1) / 20 * 1e3
+        res.append(f"thr {thr:g}: {4.0 * B * H * Lq * Lk * 64 / u2 / 1e6:7.1f}")
+    print(f"attn B{B} H{H} Lq{Lq} Lk{Lk}: " + " | ".join(res), flush=True)
