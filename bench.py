@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the separate VAE encode/decode timing (SURVEY.md §8f N1)")
     ap.add_argument("--no-configs2", action="store_true", help="at --gpus 8: skip the extra batch-8-per-GPU (configs[2]) measurement")
+    ap.add_argument("--attn", choices=("bf16", "fp8"), default="bf16",
+                    help="fp8 = BASELINE.json configs[4]: e4m3 attention operands on the MX-scaled fp8 MFMA (looser parity; NOT the headline)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -104,6 +106,7 @@ def main():
         projection_class_embeddings_input_dim=1024, sample_size=64)
     unet.load_state_dict(sd)
     unet.to(dev)
+    unet.set_attention_precision(args.attn)
     sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                           clip_sample=False, set_alpha_to_one=False, steps_offset=1)  # notebook cell 15
     pipe = Stage2_InpaintDiffusionPipeline(unet, sched)
@@ -156,13 +159,14 @@ def main():
     result = {
         "metric": "images/sec (50-step DDIM, 352x512 stage2)", "value": round(value, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.attn == "bf16" else "bf16 (attention: fp8 e4m3)",
+        "data": "synthetic",
         "config": {"workload": f"stage2 inpaint, {args.width}x{args.height} (canvas {2 * args.width}x{args.height}, "
                                f"latent {h}x{w}), batch={N} per GPU, {args.ddim_steps} DDIM steps, guidance 2.0 (UNet batch {2 * N}), "
                                "868.9M-param UNet, 258 context tokens, bf16 MFMA / fp32 accumulate",
                    "global_batch": world * N, "ms_per_denoise_step": round(ms_per_step / args.ddim_steps, 3),
                    "parallelism": f"dp{world}", "hipgraph": not args.no_graph, "setup_s": round(setup_s, 1),
-                   "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                   "rccl_world_size": dist.get_world_size() if use_dist else 1, "attention": args.attn,
                    "e2e_tflops_per_gpu": round(e2e_tflops, 1),
                    "flops_note": "e2e_tflops_per_gpu and roofline.e2e_frac credit the UN-HOISTED algorithmic FLOPs of SURVEY.md §8d "
                                  "(118.84 TFLOP per image); executed FLOPs are ~3.5% lower: the cross-attention K/V projections run once "

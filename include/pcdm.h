@@ -108,6 +108,16 @@ int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, cons
 int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                         void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s);
 
+/* ---- N4 (BASELINE.json configs[4]): the same attention with OCP e4m3 operands on the MX-scaled fp8 MFMA (unit block
+ *      scales; twice the bf16 matrix rate).  No reference counterpart (attention enters at stage2_batchtest_inpaint_model.py:133).
+ * pcdm_quantize_fp8: y[r, c] = e4m3(sat(x[r, c] * scale)) for bf16 x [rows, ldx] -> bytes y [rows, ldy]; columns [cols, cols_pad) are
+ *   written as zero (cols_pad % 8 == 0).  Used for K [B*Lk, C] and V^T [B*C, Lk -> padded to a multiple of 16].
+ * pcdm_flash_attn_fp8: q bf16 as in pcdm_flash_attn; k8 [B*Lk, ldk] / vt8 [B, H*64, ldvt] e4m3 bytes (ldk, ldvt multiples of 16,
+ *   ldvt >= Lk, padding zero); k_descale / v_descale undo the quantisation scales; thr_log2 <= 8.  fp32 softmax, P rounded to e4m3. */
+int pcdm_quantize_fp8(const void* x, void* y, int64_t rows, int cols, int cols_pad, int64_t ldx, int64_t ldy, float scale, pcdm_stream_t s);
+int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, int64_t ldk, const void* vt8, int64_t ldvt, void* o, int64_t ldo,
+                        int B, int H, int Lq, int Lk, float scale, float k_descale, float v_descale, float thr_log2, pcdm_stream_t s);
+
 /* ---- K12 time / class embedding helpers.
  * pcdm_timestep_embedding: diffusers Timesteps(dim, flip_sin_to_cos, shift) (ref :184,677): out fp32 [B,dim];
  *   t read from DEVICE memory: t_dev[step_dev ? *step_dev : 0] (int64), broadcast over B.

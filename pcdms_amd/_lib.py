@@ -52,6 +52,8 @@ _SIGS = {
     "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),
     "pcdm_flash_attn": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_flash_attn_thr": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _P], C.c_int),
+    "pcdm_quantize_fp8": ([_P, _P, _L, _I, _I, _L, _L, _F, _P], C.c_int),
+    "pcdm_flash_attn_fp8": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _F, _F, _P], C.c_int),
     "pcdm_timestep_embedding": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_small_linear": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "pcdm_assemble_input": ([_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P], C.c_int),

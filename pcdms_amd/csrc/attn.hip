@@ -204,7 +204,179 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
             }
     }
 }
+// ---- N4: the same attention with e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), twice the
+// bf16 MFMA rate: K and V^T arrive quantised (pcdm_quantize_fp8: once per projection, every query block re-reads them), Q is scaled and
+// converted once per workgroup, P is converted as it leaves the exp.  Per 64-key tile a wave issues 2 (QK^T, one per 32 keys: K = 64
+// covers head_dim) + 2 (PV, one per 32 output dims: K = 64 covers the tile's keys) + 1 (row sums) fp8 MFMAs of 64 cycles and the two
+// bf16 MFMAs that subtract the softmax reference -- 384 cycles against 704 of the bf16 kernel; the VALU work (one exp per score,
+// maxima, conversions) is unchanged, so this pays exactly because the bf16 kernel has its matrix and vector pipes evenly loaded.
+// Key order inside a tile: MFMA row i of S^T holds key e | g<<2 | h<<4 for i = e | h<<2 | g<<3, which leaves each lane half with 16
+// CONSECUTIVE keys per 32-key fragment -- the 32 bytes of its P^T operand are then [frag 0: keys 16h..16h+15 | frag 1: 32+16h..],
+// and the V^T operand of the same k-slots is two plain 16-byte reads.
+__global__ __launch_bounds__(256, 3) void flash_attn_fp8_kernel(const u16* __restrict__ q, int64_t ldq, const uint8_t* __restrict__ k8,
+                                                                int64_t ldk, const uint8_t* __restrict__ vt8, int64_t ldvt,
+                                                                u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk, float c, float thr,
+                                                                float out_scale) {
+    // K tile [64 keys][64 B of d] and V^T tile [64 d][64 B of keys], 2 stages each; 64-byte rows, 16-byte chunks XOR-swizzled by
+    // (row>>2)&3 on the DMA source and on the reads (four rows share a 256-byte bank row)
+    __shared__ __attribute__((aligned(16))) uint8_t KV[2][2][KB * 64];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QPB + wave * QPW;
+    const int hh = lane >> 5, col = lane & 31;
+
+    // Q operand (B of S^T = K Q^T): lane -> query col, its 32 bytes = d 32*hh .. +31, scaled to log2 units
+    int qrow = q0 + col;
+    const bool qvalid = qrow < Lq;
+    if (!qvalid) qrow = Lq - 1;
+    const u16* qp = q + ((int64_t)b * Lq + qrow) * ldq + h * 64 + hh * 32;
+    u32x8 qf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u16x8 raw = *(const u16x8*)(qp + i * 8);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(raw[e]) * c, -448.f), 448.f);
+        qf[2 * i] = pack4_fp8(f[0], f[1], f[2], f[3]);
+        qf[2 * i + 1] = pack4_fp8(f[4], f[5], f[6], f[7]);
+    }
+
+    // LDS-DMA staging: one K and one V^T instruction per wave per tile (1 KiB = 16 rows of 64 B each)
+    constexpr uint32_t kOOB = 0x80000000u;
+    const int srow = lane >> 2, spos = lane & 3;
+    const int rl = wave * 16 + srow;                      // tile row: key (K) / d (V^T)
+    const int gch = spos ^ ((rl >> 2) & 3);               // global 16-byte chunk stored at position spos
+    const BufRsrc rs_k = make_buf_rsrc(k8 + (int64_t)b * Lk * ldk + h * 64);
+    const BufRsrc rs_v = make_buf_rsrc(vt8 + ((int64_t)(b * H + h) * 64) * ldvt);
+    const uint32_t k_off = (uint32_t)((int64_t)rl * ldk) + gch * 16u;
+    const uint32_t v_off = (uint32_t)((int64_t)rl * ldvt) + gch * 16u;
+    auto issue_tile = [&](int key0, int buf) {
+        buf_glds16(rs_k, key0 + rl < Lk ? k_off : kOOB, (uint32_t)((int64_t)key0 * ldk), &KV[buf][0][wave * 1024]);
+        buf_glds16(rs_v, key0 + gch * 16 < ldvt ? v_off : kOOB, (uint32_t)key0, &KV[buf][1][wave * 1024]);
+    };
+
+    f32x16 oacc[2], lacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = lacc[r] = 0.f;
+    float m_ref = 0.f;
+    u16x8 qm = {0, 0, 0, 0, 0, 0, 0, 0};
+    const u16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+    const u32x8 ones8 = {0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u, 0x38383838u};   // e4m3 1.0
+
+    const int pi = (col & 3) | ((col & 0x18) >> 1) | ((col & 4) << 2);   // MFMA row i = e | h<<2 | g<<3  ->  key e | g<<2 | h<<4
+    const int sw_k = (pi >> 2) & 3, sw_v = (col >> 2) & 3;                // (fragment rows are 32-aligned: (row>>2)&3 of the row in the tile)
+    const int nkb = (Lk + KB - 1) / KB;
+
+    auto tile_step = [&](int kb, auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
+        const int key0 = kb * KB;
+        glds_wait();
+        __syncthreads();
+        if (kb + 1 < nkb) issue_tile(key0 + KB, cur ^ 1);
+        // ---- S^T = K Q^T: lane's 32 bytes of K row pi (+32 per fragment) = chunks 2hh, 2hh+1
+        u32x8 kfr[2];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) {
+            const uint8_t* kr = &KV[cur][0][(kf * 32 + pi) * 64];
+            const u32x4 lo = *(const u32x4*)(kr + (((2 * hh) ^ sw_k) * 16)), hi = *(const u32x4*)(kr + (((2 * hh + 1) ^ sw_k) * 16));
+            kfr[kf] = u32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        f32x16 s[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_f8_32x32x64(kfr[kf], qf, s[kf]);
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(ones, qm, s[kf]);   // S' = S - m_ref
+        // V^T operands of this tile (their LDS latency hides behind the softmax): row d = 32 df + col, k-slots [16hh.. | 32+16hh..]
+        u32x8 vfr[2];
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            const uint8_t* vr = &KV[cur][1][(df * 32 + col) * 64];
+            const u32x4 lo = *(const u32x4*)(vr + ((hh ^ sw_v) * 16)), hi = *(const u32x4*)(vr + (((2 + hh) ^ sw_v) * 16));
+            vfr[df] = u32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        PCDM_SCHED_BARRIER();
+        // lane holds: s[kf][r] = score(query col, key key0 + 32 kf + 16 hh + r)
+        if (key0 + KB > Lk) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + 32 * kf + 16 * hh + r >= Lk) s[kf][r] = -1e30f;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const bool bump = kb == 0 || mx > thr;
+        if (wave_any(bump)) {
+            const float m_new = bump ? bf2f(f2bf(m_ref + mx)) : m_ref;
+            const float delta = m_new - m_ref;
+            const float alpha = fast_exp2(-delta);
+            m_ref = m_new;
+            qm[0] = hh == 0 ? f2bf(-m_new) : (u16)0;
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kf][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                oacc[0][r] *= alpha;
+                oacc[1][r] *= alpha;
+            }
+            lacc[0] *= alpha;
+        }
+        // P^T operand: byte 16 kf + r  <->  key 32 kf + 16 hh + r (P <= 2^thr <= 448: no clamp needed)
+        u32x8 pf;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                pf[4 * kf + j] = pack4_fp8(fast_exp2(s[kf][4 * j]), fast_exp2(s[kf][4 * j + 1]), fast_exp2(s[kf][4 * j + 2]),
+                                           fast_exp2(s[kf][4 * j + 3]));
+#pragma unroll
+        for (int df = 0; df < 2; ++df) oacc[df] = mfma_f8_32x32x64(vfr[df], pf, oacc[df]);
+        lacc = mfma_f8_32x32x64(ones8, pf, lacc);
+    };
+
+    issue_tile(0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        tile_step(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < nkb) tile_step(kb + 1, std::integral_constant<int, 1>{});
+    }
+    const float inv = out_scale / lacc[0];
+    if (qvalid) {
+        u16* op = o + ((int64_t)b * Lq + qrow) * ldo + h * 64;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                u16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = f2bf(oacc[df][4 * rg + e] * inv);
+                *(u16x4*)(op + df * 32 + 8 * rg + 4 * hh) = ov;
+            }
+    }
+}
 }  // namespace
+
+extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, int64_t ldk, const void* vt8, int64_t ldvt, void* o,
+                                   int64_t ldo, int B, int H, int Lq, int Lk, float scale, float k_descale, float v_descale,
+                                   float thr_log2, pcdm_stream_t s) {
+    if (!q || !k8 || !vt8 || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
+    if (ldq % 8 || ldk % 16 || ldvt % 16 || ldo % 4 || ldvt < Lk) return -1;
+    if (!(thr_log2 >= 0.f) || thr_log2 > 8.f || !(k_descale > 0.f) || !(v_descale > 0.f)) return -1;   // P <= 2^thr must stay below 448
+    if ((int64_t)Lk * ldk >= 0x7fffffffLL || (int64_t)64 * ldvt >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
+    const dim3 grid((Lq + QPB - 1) / QPB, H, B);
+    PCDM_LAUNCH(flash_attn_fp8_kernel, grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const uint8_t*)k8, ldk, (const uint8_t*)vt8,
+                ldvt, (u16*)o, ldo, H, Lq, Lk, scale * k_descale * 1.44269504088896341f, thr_log2, v_descale);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                    void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s) {

@@ -383,6 +383,40 @@ extern "C" int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_ep
     return 0;
 }
 
+// bf16 [rows, ldx] -> e4m3 [rows, ldy] (bytes), y = sat(x * scale); 8 elements per thread (16 B in, 8 B out); columns >= cols of a row
+// (up to cols_pad) are written as zero: the K / V^T operands of pcdm_flash_attn_fp8
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const u16* __restrict__ x, uint8_t* __restrict__ y, int64_t rows, int cols,
+                                                           int cols_pad, int64_t ldx, int64_t ldy, float scale) {
+    const int per_row = cols_pad / 8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const int64_t r = i / per_row;
+    const int c = (int)(i - r * per_row) * 8;
+    float v[8];
+    if (c + 8 <= cols && (ldx & 7) == 0) {   // (rows start 16-byte aligned)
+        const u16x8 a = *(const u16x8*)(x + r * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(a[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c + e < cols ? bf2f(x[r * ldx + c + e]) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * scale, -448.f), 448.f);
+    u32x2 o = {pack4_fp8(v[0], v[1], v[2], v[3]), pack4_fp8(v[4], v[5], v[6], v[7])};
+    *(u32x2*)(y + r * ldy + c) = o;
+}
+
+extern "C" int pcdm_quantize_fp8(const void* x, void* y, int64_t rows, int cols, int cols_pad, int64_t ldx, int64_t ldy, float scale,
+                                 pcdm_stream_t s) {
+    if (!x || !y || rows <= 0 || cols <= 0 || cols_pad < cols || cols_pad % 8 || ldy % 8 || ldy < cols_pad || ldx < cols) return -1;
+    const int64_t total = rows * (cols_pad / 8);
+    PCDM_LAUNCH(quantize_fp8_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, (const u16*)x, (uint8_t*)y, rows, cols, cols_pad,
+                ldx, ldy, scale);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pcdm_softmax_rows(const float* s_in, void* p_out, int rows, int cols, int64_t ld_s, int64_t ld_p, float scale,
                                  pcdm_stream_t s) {
     if (!s_in || !p_out || rows <= 0 || cols <= 0 || cols > 8192) return -1;

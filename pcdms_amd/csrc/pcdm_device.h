@@ -17,6 +17,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 #define PCDM_WAVE 64
 
@@ -208,6 +209,72 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(u16x8 a, u16x8 b, f32x4 c) {
 #else
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// ---- OCP fp8 e4m3 (gfx950: e4m3fn -- bias 7, max 448, no infinities; NOT MI300's fnuz) --------------------------------------
+// decode / encode on the host side of the emulator and in tests; the GPU converts with v_cvt_pk_fp8_f32 (RNE)
+__device__ __forceinline__ float fp8_e4m3_to_f(uint32_t v) {
+    const uint32_t s = (v >> 7) & 1, e = (v >> 3) & 15, m = v & 7;
+    float f;
+    if (e == 0) f = (float)m * 0.001953125f;                         // subnormal: m * 2^-9
+    else if (e == 15 && m == 7) f = __builtin_nanf("");
+    else f = (1.0f + (float)m * 0.125f) * __builtin_bit_cast(float, (uint32_t)((e + 120) << 23));   // 2^(e-7)
+    return s ? -f : f;
+}
+__device__ __forceinline__ uint32_t f_to_fp8_e4m3(float f) {      // RNE, saturating at +-448 (software: emulator / references)
+    const uint32_t s = f < 0.f ? 0x80u : 0u;
+    float a = f < 0.f ? -f : f;
+    if (!(a == a)) return s | 0x7f;
+    if (a >= 448.f) return s | 0x7e;
+    if (a < 0.0009765625f) return s;                                 // < 2^-10: rounds to zero (ties-to-even at exactly 2^-10 -> 0)
+    int e = (int)((__builtin_bit_cast(uint32_t, a) >> 23) & 255) - 127;
+    if (e < -6) e = -6;                                              // subnormal range: quantum 2^-9
+    const float q = __builtin_bit_cast(float, (uint32_t)((e - 3 + 127) << 23));   // 2^(e-3): one mantissa step
+    const float r = __builtin_rintf(a / q);                          // RNE on the grid
+    const float v = r * q;
+    if (v >= 448.f) return s | 0x7e;
+    const uint32_t bits = __builtin_bit_cast(uint32_t, v);
+    const int ev = (int)((bits >> 23) & 255) - 127;
+    if (v < 0.015625f) return s | (uint32_t)(v * 512.f);             // subnormal: m = v / 2^-9
+    return s | (uint32_t)((ev + 7) << 3) | ((bits >> 20) & 7);
+}
+// four fp32 -> one dword of four e4m3 (byte 0 = first)
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+#ifdef PCDM_EMU
+    return f_to_fp8_e4m3(a) | (f_to_fp8_e4m3(b) << 8) | (f_to_fp8_e4m3(c) << 16) | (f_to_fp8_e4m3(d) << 24);
+#else
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+#endif
+}
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands e4m3 and unit block scales (E8M0 127 = 2^0): D[i][j] += sum_k A[i][k] B[j][k],
+// k = 0..63, at twice the bf16 rate.  A lane l -> row (l&31), its 32 bytes = k 32*(l>>5) .. +31 in order; B likewise with column
+// (l&31); D as every 32x32 MFMA: lane l, reg r -> col (l&31), row (r&3) + 8*(r>>2) + 4*(l>>5).
+__device__ __forceinline__ f32x16 mfma_f8_32x32x64(u32x8 a, u32x8 b, f32x16 c) {
+#ifdef PCDM_EMU
+    struct P { uint32_t a[8], b[8]; } p;
+    for (int e = 0; e < 8; ++e) { p.a[e] = a[e]; p.b[e] = b[e]; }
+    static_assert(sizeof(P) == emu::kSlot, "payload fills one exchange slot");
+    const char* all = emu::wave_exchange(&p, sizeof(p));
+    const int l = emu::lane_id(), j = l & 31, hh = l >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float s = c[r];
+        for (int k = 0; k < 64; ++k) {
+            const P* pa = (const P*)(all + (i + 32 * (k >> 5)) * emu::kSlot);
+            const P* pb = (const P*)(all + (j + 32 * (k >> 5)) * emu::kSlot);
+            const int kb = k & 31;
+            s += fp8_e4m3_to_f((pa->a[kb >> 2] >> (8 * (kb & 3))) & 255) * fp8_e4m3_to_f((pb->b[kb >> 2] >> (8 * (kb & 3))) & 255);
+        }
+        d[r] = s;
+    }
+    return d;
+#else
+    typedef int i32x8_ __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(i32x8_, a), __builtin_bit_cast(i32x8_, b), c, 0, 0, 0,
+                                                           0x7f7f7f7f, 0, 0x7f7f7f7f);
 #endif
 }
 

@@ -360,6 +360,38 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
     return out
 
 
+FP8 = torch.uint8   # e4m3 bytes (torch.float8_e4m3fn views of these buffers are never computed on by PyTorch)
+
+
+def quantize_fp8(x: torch.Tensor, out: torch.Tensor, cols: Optional[int] = None, scale: float = 1.0) -> torch.Tensor:
+    """bf16 [rows, >= cols] (row stride = .stride(0)) -> e4m3 bytes out [rows, cols_pad]; columns >= cols are zeroed."""
+    assert x.dtype == BF16 and out.dtype == FP8 and x.stride(-1) == 1 and out.stride(-1) == 1 and x.dim() == 2 and out.dim() == 2
+    rows = x.shape[0]
+    cols = cols if cols is not None else x.shape[1]
+    _chk(_lib.lib().pcdm_quantize_fp8(_ptr(x), _ptr(out), rows, cols, out.shape[1], x.stride(0), out.stride(0), float(scale), _stream(x)),
+         "pcdm_quantize_fp8")
+    return out
+
+
+def flash_attn_fp8(q: torch.Tensor, k8: torch.Tensor, vt8: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int, Lk: int,
+                   scale: Optional[float] = None, k_descale: float = 1.0, v_descale: float = 1.0, thr: float = 5.0) -> torch.Tensor:
+    """q bf16 [B*Lq, ldq]; k8 e4m3 [B*Lk, ldk]; vt8 e4m3 [B, H*64, ldvt]; out bf16 [B*Lq, ldo]."""
+    assert q.dtype == BF16 and out.dtype == BF16 and k8.dtype == FP8 and vt8.dtype == FP8
+    assert q.stride(1) == 1 and k8.stride(1) == 1 and vt8.is_contiguous() and out.stride(1) == 1
+    scale = scale if scale is not None else 1.0 / math.sqrt(64)
+    log = LAUNCH_LOG is not None and q.is_cuda
+    if log:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().pcdm_flash_attn_fp8(_ptr(q), q.stride(0), _ptr(k8), k8.stride(0), _ptr(vt8), vt8.shape[-1], _ptr(out), out.stride(0),
+                                       B, H, Lq, Lk, scale, float(k_descale), float(v_descale), float(thr), _stream(q))
+    _chk(rc, "pcdm_flash_attn_fp8")
+    if log:
+        e1.record()
+        LAUNCH_LOG.append(("flash_attn_fp8_kernel", 4.0 * B * H * Lq * Lk * 64, e0, e1, (B, H, Lq, Lk)))
+    return out
+
+
 # ------------------------------------------------------------------------------------ small ops
 def timestep_embedding(t_dev: torch.Tensor, step_dev: Optional[torch.Tensor], out: torch.Tensor, flip: bool = True,
                        shift: float = 0.0) -> torch.Tensor:

@@ -339,6 +339,51 @@ def test_flash_attn(backend, case):
         close(o2, ref, tol=1.5e-2)
 
 
+def _e4m3(x: torch.Tensor) -> torch.Tensor:
+    """OCP e4m3fn round trip (RNE, saturating) -- torch's own float8_e4m3fn cast, used only as the test's quantiser."""
+    return x.float().clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("case", ["self", "cross258", "tiny88", "spike"])
+def test_flash_attn_fp8(backend, case):
+    """N4: e4m3 K / V^T / Q / P on the MX-scaled fp8 MFMA.  Two checks:
+    * against the fp32 softmax attention of the SAME quantised operands (q*c, K, V rounded to e4m3 as the kernel does): what is left
+      is the e4m3 rounding of P and fp32 summation order -- rel-L2 <= 4e-2;
+    * against the un-quantised fp32 attention: the stated fp8 tolerance of this path, rel-L2 <= 8e-2 (bf16 kernel: 1.5e-2 max-abs)."""
+    dev = backend.device
+    if backend.is_emu:
+        B, H, Lq, Lk = {"self": (1, 2, 70, 70), "cross258": (1, 1, 40, 66), "tiny88": (2, 1, 24, 24), "spike": (1, 1, 33, 130)}[case]
+    else:
+        B, H, Lq, Lk = {"self": (8, 5, 5632, 5632), "cross258": (4, 10, 1408, 258), "tiny88": (8, 20, 88, 88), "spike": (2, 5, 1408, 1408)}[case]
+    Cc = H * 64
+    q, k, v = rnd(B * Lq, Cc, seed=70), rnd(B * Lk, Cc, seed=71), rnd(B * Lk, Cc, seed=72)
+    if case == "spike":
+        k = k.clone()
+        k[Lk - 3] = (q[5].float() * 6).to(BF16)
+        k[Lk // 2] = (q[7].float() * 3).to(BF16)
+    # quantised operands through the library's own kernel; checked against torch's e4m3 cast
+    Lp = (Lk + 15) // 16 * 16
+    k8 = torch.empty(B * Lk, Cc, dtype=torch.uint8, device=dev)
+    ops.quantize_fp8(k.to(dev), k8)
+    vt = v.view(B, Lk, Cc).permute(0, 2, 1).contiguous().view(B * Cc, Lk)
+    vt8 = torch.full((B * Cc, Lp), 0x7f, dtype=torch.uint8, device=dev)
+    ops.quantize_fp8(vt.to(dev), vt8, cols=Lk)
+    backend.sync()
+    assert torch.equal(k8.cpu().view(torch.float8_e4m3fn).float(), _e4m3(k))
+    assert torch.equal(vt8.cpu().view(torch.float8_e4m3fn).float()[:, :Lk], _e4m3(vt)) and (vt8.cpu()[:, Lk:] == 0).all()
+    out = torch.empty(B * Lq, Cc, dtype=BF16, device=dev)
+    ops.flash_attn_fp8(q.to(dev), k8, vt8.view(B, Cc, Lp), out, B, H, Lq, Lk)
+    backend.sync()
+    c = 0.125 * 1.44269504088896341
+    qq = (_e4m3(q.float() * c) / c).to(torch.float32)
+    ref_q = _attn_ref(qq, _e4m3(k), _e4m3(v), B, H, Lq, Lk)
+    ref = _attn_ref(q, k, v, B, H, Lq, Lk)
+    o = out.float().cpu()
+    r1 = ((o - ref_q).norm() / ref_q.norm()).item()
+    r2 = ((o - ref).norm() / ref.norm()).item()
+    assert torch.isfinite(o).all() and r1 <= 4e-2 and r2 <= 8e-2, (r1, r2)
+
+
 # ------------------------------------------------------------------------------------------------ small ops
 def test_timestep_embedding_and_small_linear(backend):
     dev = backend.device

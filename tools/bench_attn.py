@@ -39,4 +39,23 @@ for (H, Lq, Lk) in [(5, 5632, 5632), (10, 1408, 1408), (20, 352, 352), (5, 5632,
         e1.synchronize()
         u2 = e0.elapsed_time(e1) / 20 * 1e3
         res.append(f"thr {thr:g}: {4.0 * B * H * Lq * Lk * 64 / u2 / 1e6:7.1f}")
+    # N4: e4m3 operands (K / V^T quantised once, outside the timed region: they are reused by every query block)
+    Lp = (Lk + 15) // 16 * 16
+    k8 = ops.quantize_fp8(k, torch.empty(B * Lk, C, dtype=torch.uint8, device=dev))
+    vt8 = ops.quantize_fp8(vt.view(B * C, -1), torch.zeros(B * C, Lp, dtype=torch.uint8, device=dev), cols=Lk).view(B, C, Lp)
+    for _ in range(3):
+        ops.flash_attn_fp8(q, k8, vt8, out, B, H, Lq, Lk)
+    e0.record()
+    for _ in range(20):
+        ops.flash_attn_fp8(q, k8, vt8, out, B, H, Lq, Lk)
+    e1.record()
+    e1.synchronize()
+    u8 = e0.elapsed_time(e1) / 20 * 1e3
+    e0.record()
+    for _ in range(20):
+        ops.quantize_fp8(k, k8)
+        ops.quantize_fp8(vt.view(B * C, -1), vt8.view(B * C, Lp), cols=Lk)
+    e1.record()
+    e1.synchronize()
+    res.append(f"fp8: {u8:8.1f} us {4.0 * B * H * Lq * Lk * 64 / u8 / 1e6:7.1f} TF/s (+ quantise K,V^T {e0.elapsed_time(e1) / 20 * 1e3:.1f} us)")
     print(f"attn B{B} H{H} Lq{Lq} Lk{Lk}: " + " | ".join(res), flush=True)
