@@ -28,6 +28,8 @@
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {
@@ -35,6 +37,9 @@ constexpr int KB = 64;     // keys per tile
 constexpr int QPW = 32;    // queries per wave
 constexpr int QPB = 128;   // queries per workgroup
 
+// ROWSUM_VALU: the softmax denominator as per-lane fp32 adds of the un-rounded P (combined across the two lane halves once, at the
+// end) instead of an MFMA against a ones fragment (4 of the 22 MFMAs per tile); which one wins depends on which pipe has slack.
+template <bool ROWSUM_VALU>
 __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
                                                          const u16* __restrict__ k, int64_t ldk,
                                                          const u16* __restrict__ vt, int64_t ldvt,
@@ -170,17 +175,30 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
             lacc[0] *= alpha;   // only register 0 is ever read back: l = l*alpha + sum_k P (added by the MFMA below)
         }
         u16x8 pf[4];
+        if constexpr (ROWSUM_VALU) {
+            float part[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains
 #pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
+            for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pf[2 * kf + (r >> 3)][r & 7] = f2bf(fast_exp2(s[kf][r]));
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(s[kf][r]);
+                    part[r & 3] += pv;
+                    pf[2 * kf + (r >> 3)][r & 7] = f2bf(pv);
+                }
+            lacc[0] += (part[0] + part[1]) + (part[2] + part[3]);
+        } else {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pf[2 * kf + (r >> 3)][r & 7] = f2bf(fast_exp2(s[kf][r]));
+        }
         // ---- O^T += V^T P^T ; row sums += 1^T P^T (the softmax denominator is accumulated by the matrix pipe,
         //      which has slack here, instead of 32 VALU adds per tile -- the kernel is VALU-bound at d = 64)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
             for (int df = 0; df < 2; ++df) oacc[df] = mfma_32x32x16(vfr[s4][df], pf[s4], oacc[df]);
-            lacc = mfma_32x32x16(ones, pf[s4], lacc);
+            if constexpr (!ROWSUM_VALU) lacc = mfma_32x32x16(ones, pf[s4], lacc);
         }
     };
 
@@ -189,7 +207,8 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
         tile_step(kb, std::integral_constant<int, 0>{});
         if (kb + 1 < nkb) tile_step(kb + 1, std::integral_constant<int, 1>{});
     }
-    const float l_tot = lacc[0];   // sum over all keys (the MFMA contracts over both lane halves)
+    // sum over all keys: the MFMA contracts over both lane halves; the VALU partial sums are combined here
+    const float l_tot = ROWSUM_VALU ? lacc[0] + __shfl_xor(lacc[0], 32, 64) : lacc[0];
     const float inv = 1.0f / l_tot;
     if (qvalid) {
         u16* op = o + ((int64_t)b * Lq + qrow) * ldo + h * 64;
@@ -378,6 +397,9 @@ extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, i
     return 0;
 }
 
+// A/B switch of the row-sum path (tools/bench_attn.py; PCDM_ATTN_ROWSUM=valu|mfma in the environment at load time)
+static bool g_rowsum_valu = [] { const char* e = getenv("PCDM_ATTN_ROWSUM"); return e && e[0] == 'v'; }();
+
 extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                    void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s) {
     if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
@@ -385,8 +407,12 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
-    PCDM_LAUNCH(flash_attn_kernel, grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
-                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2);
+    if (g_rowsum_valu)
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<true>), grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
+                    (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2);
+    else
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<false>), grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
+                    (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -33,6 +33,7 @@ from tests.test_unet import _kwargs
 
 FIXTURE = Path(__file__).resolve().parent / "golden" / "fullsize_config2.npz"
 FWD_TOL = 2.5e-2      # one forward, rel-L2 of the guided eps: the suite's forward tolerance (tests/test_unet.py); measured 0.95e-2 .. 1.67e-2
+FP8_FWD_TOL = 6e-2    # one forward with fp8 (e4m3) attention operands -- configs[4]'s own, looser tolerance
 TRAJ_TOL = 5e-3       # latents along / at the end of the 50-step trajectory (measured 0.7e-3 .. 0.8e-3: the DDIM update is dominated by
                       # its deterministic rescale of the latents, which both sides compute in fp32)
 PIX_TOL = 1.0         # mean absolute difference in uint8 levels over a canvas (measured 0.34; bf16 VAE alone 0.34)
@@ -127,6 +128,24 @@ def test_50_step_trajectory_and_pixels(full):
     print("full-size uint8 canvases: mean|diff| levels", {k: round(v, 3) for k, v in pix.items()}, "VAE alone", {k: round(v, 3) for k, v in pix_vae.items()},
           "canvas-mean diff", np.round(means, 3).tolist())
     assert max(pix.values()) <= PIX_TOL and max(pix_vae.values()) <= PIX_TOL and means.max() <= PIX_MEAN_TOL, (pix, pix_vae, means)
+
+
+@pytest.mark.gpu
+def test_fp8_attention_forward_at_oracle_states(full):
+    """BASELINE.json configs[4]: the same full-size forward with every attention on e4m3 operands.  Its own stated
+    tolerance: rel-L2 <= FP8_FWD_TOL against the fp32 oracle (the bf16-attention path: FWD_TOL)."""
+    fx, cfg, m, dev = full
+    N, h, w = 4, 64, 88
+    inp = synth_inputs(cfg, h, w, N)
+    sch = DDIMOracle()
+    sch.set_timesteps(int(fx["steps"]))
+    m.set_attention_precision("fp8")
+    try:
+        rels = {i: _rel(_guided_eps(m, cfg, inp, torch.from_numpy(fx[f"lat_{i}"]), sch.timesteps[i], N, dev), fx[f"eps_{i}"]) for i in (0, 25, 49)}
+    finally:
+        m.set_attention_precision("bf16")
+    print("full-size single-forward rel-L2 with fp8 attention:", {k: round(v, 5) for k, v in rels.items()})
+    assert max(rels.values()) <= FP8_FWD_TOL, rels
 
 
 @pytest.mark.gpu
