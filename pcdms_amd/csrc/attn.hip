@@ -39,6 +39,7 @@ constexpr int QPB = 128;   // queries per workgroup
 
 // ROWSUM_VALU: the softmax denominator as per-lane fp32 adds of the un-rounded P (combined across the two lane halves once, at the
 // end) instead of an MFMA against a ones fragment (4 of the 22 MFMAs per tile); which one wins depends on which pipe has slack.
+// (s_setprio 1 around the two MFMA clusters was measured too: no gain with 3 co-resident waves per SIMD -- removed.)
 template <bool ROWSUM_VALU>
 __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
                                                          const u16* __restrict__ k, int64_t ldk,
@@ -407,12 +408,12 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
-    if (g_rowsum_valu)
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<true>), grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
-                    (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2);
-    else
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<false>), grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,
-                    (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2);
+#define PCDM_ATTN_LAUNCH(RS)                                                                                                            \
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
+                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2)
+    if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true);
+    else PCDM_ATTN_LAUNCH(false);
+#undef PCDM_ATTN_LAUNCH
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -18,6 +18,7 @@ constexpr int kGnUnroll = 4;   // independent 16-byte loads in flight per thread
                                // 128 chunks x 8 loads was 25 % slower at 64x88 (per-block reduction tail dominates)
 constexpr int kGnMaxC = 4096;
 constexpr int kThreads = 256;
+constexpr int kGnClusterMaxWgs = 256;   // one workgroup per CU: every partner of a cluster is resident, whatever the dispatch order
 
 struct GnGeom {
     int noct, tpr, rows_par;
@@ -319,6 +320,139 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict
     }
 }
 
+// ---- single-pass GroupNorm for slabs that do NOT fit one workgroup (UNet level 0: 5632 rows; level 1 at C = 640 with only 128
+// slabs): the rows of a (batch, group set) slab are split over S workgroups that each keep their chunk in registers, publish their
+// per-group {sum, sum of squares} and wait for the other S - 1 (agent-scope write-through stores -> drained -> ticket; relaxed poll ->
+// agent-scope loads: cdna_hip_programming.md Guideline 16, the fence-free form), then every workgroup finishes the statistics itself (fixed chunk order, fp64: bit-identical
+// in all of them and run to run) and normalises its rows: 2 bytes moved per element and ONE launch, where the two-kernel path moves 3
+// in two launches.  The grid is at most one workgroup per CU, so all S partners are resident (no deadlock); the counters are
+// self-resetting (the last workgroup to have READ the partials clears them; the next launch cannot start before this one ends).
+// ws layout: [slab][S][4 groups][2] floats, then [slab][2] unsigned counters (arrived, read) -- zeroed once by the caller.
+template <int THREADS, int MAXR>
+__global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restrict__ x1, int C1, const u16* __restrict__ x2, int C2, int B,
+                                                            int HW, int gs, int gpb, int noct, int S, int rows_per_chunk, float eps,
+                                                            double inv_n /* 1 / (HW * gs) */, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int fuse_silu, u16* __restrict__ y,
+                                                            float* __restrict__ ws) {
+    __shared__ float red[(THREADS / 64) * 4];
+    __shared__ float stat[8];                    // {mean, rstd} of the <= 4 groups of this slab
+    const int C = C1 + C2;
+    const int nslab = gridDim.x / S;
+    const int slab = blockIdx.x % nslab, chunk = blockIdx.x / nslab;   // partners are nslab apart: different XCDs do not matter here
+    const int b = slab % B, gset = slab / B;
+    const int t = threadIdx.x;
+    const int rows_par = THREADS / noct;
+    const int rp = t / noct, oc = t - rp * noct;
+    const bool active = rp < rows_par;
+    const int cl = oc * 8;
+    const int c = gset * gpb * gs + cl;
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = (r0 + rows_per_chunk < HW) ? r0 + rows_per_chunk : HW;
+    int ge[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ge[e] = (cl + e) / gs;
+    u16x8 v[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = r0 + rp + i * rows_par;
+        const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[i] = (active && r < r1) ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, c) : z;
+    }
+    // ---- this chunk's per-group sum and sum of squares (rows beyond the chunk hold zeros)
+    // (two passes over the packed registers: sums, then sums of squares -- holding both sets of accumulators and the slab
+    //  at once spills at 128 registers)
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, qg[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf2f(v[i][e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[k] += (ge[e] == k) ? s[e] : 0.f;
+    }
+    gn_block_sum4<THREADS>(sg, gpb, red);
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
+    {
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(v[i][e]);
+                q[e] += f * f;
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qg[k] += (ge[e] == k) ? q[e] : 0.f;
+    }
+    gn_block_sum4<THREADS>(qg, gpb, red);
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
+    // ---- publish, wait for the partners, finish the statistics
+    float* part = ws + (int64_t)slab * S * 8;
+    unsigned* cnt = (unsigned*)(ws + (int64_t)nslab * S * 8) + slab * 2;
+    // (payload and counter both by agent-scope accesses -- write-through stores drained before the ticket, L2-bypassing loads after
+    //  the poll: no release / acquire FENCE, whose L2 write-back of the previous kernel's still-dirty output cost ~7 us per launch here)
+    if (t < 8) pcdm_store_agent(part + chunk * 8 + t, (t & 1) ? qg[t >> 1] : sg[t >> 1]);
+    pcdm_drain_vmem();
+    __syncthreads();
+    if (t == 0) {
+        pcdm_atomic_inc_agent(cnt);
+        while (pcdm_load_agent_u32(cnt) < (unsigned)S) pcdm_sleep();
+    }
+    __syncthreads();
+    if (t < gpb) {
+        double ss = 0.0, qq = 0.0;
+        for (int ch = 0; ch < S; ++ch) {
+            ss += (double)pcdm_load_agent(part + ch * 8 + 2 * t);
+            qq += (double)pcdm_load_agent(part + ch * 8 + 2 * t + 1);
+        }
+        const double mean = ss * inv_n;            // (fp64 multiplies only: fp64 divide / sqrt sequences cost ~40 registers here)
+        double var = qq * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[2 * t] = (float)mean;
+        stat[2 * t + 1] = 1.0f / sqrtf((float)var + eps);
+    }
+    __syncthreads();
+    if (t == 0) {   // the partials have been read: the last reader re-arms the counters for the next launch
+        if (pcdm_atomic_inc_agent(cnt + 1) == (unsigned)S - 1) {
+            pcdm_store_agent_u32(cnt, 0u);
+            pcdm_store_agent_u32(cnt + 1, 0u);
+        }
+    }
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float mean = stat[2 * (ge[e] & 3)], rstd = stat[2 * (ge[e] & 3) + 1];
+        sc[e] = rstd * gamma[c + e];
+        sh[e] = beta[c + e] - mean * sc[e];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = r0 + rp + i * rows_par;
+        if (r < r1) {
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(v[i][e]) * sc[e] + sh[e];
+                if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
+                o[e] = f2bf(f);
+            }
+            *(u16x8*)(y + ((int64_t)b * HW + r) * C + c) = o;
+        }
+    }
+}
+
 template <int THREADS, int MAXR>
 void launch_gn_fused(hipStream_t st, const u16* x1, int C1, const u16* x2, int C2, int B, int HW, int groups, int gs, int gpb,
                      int noct, float eps, const float* gamma, const float* beta, int silu, u16* y) {
@@ -456,6 +590,15 @@ inline int gn_chunks(int HW, int rows_par) {
 }
 }  // namespace
 
+static bool gn_cluster_enabled() {
+#ifdef PCDM_EMU
+    return false;
+#else
+    static const bool enabled = [] { const char* e = getenv("PCDM_GN_CLUSTER"); return !(e && e[0] == '0'); }();   // A/B switch
+    return enabled;
+#endif
+}
+
 extern "C" int64_t pcdm_groupnorm_ws_floats(int B, int C) {
     (void)C;
     return (int64_t)B * kGnMaxChunks * 256 * 2;   // [B][chunks][groups <= 256][2]
@@ -478,7 +621,8 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
             const char* e = getenv("PCDM_GN_FUSED_MAX_KB");   // tuning knob (tools/bench_ops.py); 0 disables the fused path
             return (int64_t)(e ? atoi(e) : 352) * 1024;
         }();
-        if (gpb <= 4 && groups % gpb == 0 && noct <= 64 && (int64_t)HW * noct * 16 <= max_slab) {
+        const bool few_slabs = (groups / gpb) * B <= 128 && HW >= 1024;   // <= 128 long workgroups: the cluster kernel below fills the chip
+        if (gpb <= 4 && groups % gpb == 0 && noct <= 64 && (int64_t)HW * noct * 16 <= max_slab && !(few_slabs && gn_cluster_enabled())) {
             // rows per thread at 256 / 512 / 1024 threads, at most 8 (all loads of the slab in flight at once, <= 128 KiB)
             auto need = [&](int th) { return (HW + th / noct - 1) / (th / noct); };
             const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
@@ -495,6 +639,34 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
             }
         }
     }
+#ifndef PCDM_EMU   // (the lane emulator runs workgroups one after the other: workgroups that wait for each other cannot run there;
+                   //  the cluster kernel is covered by the -m gpu tests only)
+    {   // cluster path: a slab split over S workgroups, at most one workgroup per CU in total (all partners resident)
+        const int gs = C / groups;
+        int gpb = 1;
+        while (gpb <= 4 && (gpb * gs) % 8) ++gpb;
+        const int noct = gpb * gs / 8;
+        if (gn_cluster_enabled() && gpb <= 4 && groups % gpb == 0 && noct <= 64) {
+            const int nslab = (groups / gpb) * B;
+            const int rows_par = 512 / noct;   // 512 threads: 256 registers per lane, no spills with 16 rows held per thread
+            for (int S = 2; S <= 8 && nslab * S <= kGnClusterMaxWgs; S *= 2) {
+                const int rpc = (HW + S - 1) / S;
+                const int need = (rpc + rows_par - 1) / rows_par;
+                if (need > 16 || (int64_t)nslab * (S * 8 + 2) > pcdm_groupnorm_ws_floats(B, C)) continue;
+                const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
+                const double inv_n = 1.0 / ((double)HW * gs);
+                if (need <= 8)
+                    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, 8>), dim3(nslab * S), dim3(512), 0, st, a1, C1, a2, C2, B, HW, gs, gpb,
+                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, ws);
+                else
+                    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, 16>), dim3(nslab * S), dim3(512), 0, st, a1, C1, a2, C2, B, HW, gs, gpb,
+                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, ws);
+                PCDM_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+    }
+#endif
     const GnGeom g = gn_geom(C);
     const int nchunk = gn_chunks(HW, g.rows_par);
     const int rpc = (HW + nchunk - 1) / nchunk;

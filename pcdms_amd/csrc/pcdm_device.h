@@ -286,6 +286,9 @@ __device__ __forceinline__ void pcdm_acquire_agent() {}
 __device__ __forceinline__ unsigned pcdm_atomic_inc_agent(unsigned* p) { return (*p)++; }
 __device__ __forceinline__ float pcdm_load_agent(const float* p) { return *p; }
 __device__ __forceinline__ void pcdm_store_agent(float* p, float v) { *p = v; }
+__device__ __forceinline__ unsigned pcdm_load_agent_u32(const unsigned* p) { return *(volatile const unsigned*)p; }
+__device__ __forceinline__ void pcdm_store_agent_u32(unsigned* p, unsigned v) { *p = v; }
+__device__ __forceinline__ void pcdm_sleep() {}
 #else
 __device__ __forceinline__ void pcdm_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void pcdm_release_agent() {
@@ -302,6 +305,13 @@ __device__ __forceinline__ void pcdm_store_agent(float* p, float v) {   // sc1 w
 __device__ __forceinline__ float pcdm_load_agent(const float* p) {   // L2-served (bypasses this CU's L1)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned pcdm_load_agent_u32(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pcdm_store_agent_u32(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pcdm_sleep() { __builtin_amdgcn_s_sleep(2); }
 #endif
 
 // ---- wave reductions -------------------------------------------------------------------------
