@@ -186,6 +186,27 @@ __device__ __forceinline__ void wait_vm_then_barrier() {
 }
 
 template <int N>
+__device__ __forceinline__ void wait_vm_lds_then_barrier() {   // as above, and this wave's ds_reads are complete too
+#ifdef PCDM_EMU
+    __syncthreads();
+#else
+    // builtins, not inline asm: the compiler's own waitcnt insertion must SEE that the LDS counter was drained here -- behind an opaque
+    // asm it assumed the previous k-step's fragment reads were still pending and put an s_waitcnt lgkmcnt(0) between every block of
+    // ds_reads and the MFMAs that were meant to cover them (simm16: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+__device__ __forceinline__ void wait_lds() {   // s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched), visible to the compiler's scoreboard
+#ifndef PCDM_EMU
+    __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));
+#endif
+}
+
+template <int N>
 __device__ __forceinline__ void wait_vm() {
 #ifndef PCDM_EMU
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -207,8 +228,14 @@ __device__ __forceinline__ void wait_lds_then_barrier() {  // this wave's ds_rea
 // F = MFMA fragment edge: 32 (v_mfma_f32_32x32x16_bf16, 16 accumulator registers per fragment) or 16 (v_mfma_f32_16x16x32_bf16, 4):
 // the same FLOP rate and the same LDS bytes per FLOP for a given wave tile; F = 16 allows wave tiles that are multiples of 16
 // (96x80: the 192x320 / 96x320 block tiles, whose counts divide the 256 CUs for M = 45056 / 11264 / 2816).
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32>
+// KB = K-tile depth.  KB = 32 (F = 16, four stages): the same LDS bytes as two 64-deep stages, but THREE tiles of 32 in flight behind
+// the one being multiplied instead of one tile of 64 -- 96 KiB instead of 64 KiB of loads outstanding per CU.  The KB = 64 loop of the
+// 192x320 tile takes ~2.8 k cycles per K-tile whatever the problem (tools/gemm_anatomy.py), against 1.9 k cycles of MFMA issue: one
+// memory latency per K-tile, i.e. the ring is too shallow, not the matrix pipe too slow.  Loader ROLES: a DMA instruction covers
+// 16 rows of 64 bytes, so the (BM + BN) / 16 instructions of a tile are dealt out whole-operand -- waves [0, NWA) stage A, the rest B.
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32, int KB = 64>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
+    constexpr int BK = KB;                 // (shadows the file-scope default of 64)
     constexpr int NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / F, FN = WN / F;
     constexpr int KS = 512 / F;            // k per MFMA: 16 (32x32) or 32 (16x16)
@@ -217,13 +244,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NQ = F == 32 ? 4 : 1;    // accumulator quads (4 consecutive channels of one pixel) per lane per fragment
     constexpr int LF = F == 32 ? 5 : 4;    // log2(F)
     static_assert((F == 32 || F == 16) && (!STAG || F == 32), "fragment shape");
+    static_assert(KB == 64 || (KB == 32 && F == 16 && STAGES == 4 && !STAG), "K-tile depth");
     typedef typename std::conditional<F == 32, f32x16, f32x4>::type acc_t;
-    constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // LDS-DMA instructions per wave per K-tile (8 rows x 128 B each)
+    constexpr bool ROLES = KB == 32;                   // loader roles (see above)
+    constexpr int LPR = BK / 8;                        // lanes (16-byte chunks) per staged row
+    constexpr int RPI = 64 / LPR;                      // rows per LDS-DMA wave-instruction: 8 (128-byte rows) or 16 (64-byte rows)
+    constexpr int PW = ROLES ? (BM + BN) / (RPI * NW) : 0;
+    constexpr int NWA = ROLES ? BM / (RPI * PW) : NW;  // waves staging A
+    // LDS-DMA instructions per wave per K-tile, A rows / B rows
+    constexpr int AI = ROLES ? PW : BM / 8 / NW, BI = ROLES ? PW : BN / 8 / NW;
+    constexpr int PWT = ROLES ? PW : AI + BI;          // ... in total (every wave issues the same number: counted vmcnt waits)
     constexpr int D = STAGES - 1;                      // prefetch distance (tiles in flight)
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 32 == 0 && WN % F == 0, "tile shape");
+    static_assert(ROLES || (BM % (8 * NW) == 0 && BN % (8 * NW) == 0), "tile shape");
+    static_assert(!ROLES || ((BM + BN) % (RPI * NW) == 0 && BM % (RPI * PW) == 0 && BN % (RPI * PW) == 0), "tile shape (roles)");
+    static_assert(WM % 32 == 0 && WN % F == 0, "tile shape");
     PCDM_DYN_SMEM(smem);
-    u16* As = (u16*)smem;                    // [STAGES][BM][64]   (unpadded, XOR-swizzled 16-byte chunks)
-    u16* Bs = As + STAGES * BM * BK;         // [STAGES][BN][64]
+    u16* As = (u16*)smem;                    // [STAGES][BM][BK]   (unpadded, XOR-swizzled 16-byte chunks)
+    u16* Bs = As + STAGES * BM * BK;         // [STAGES][BN][BK]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform -> LDS bases / branches in SGPRs
@@ -252,16 +289,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     // CONSTANT over the K loop + a wave-uniform SGPR offset that advances with the K-tile: no per-lane address
     // arithmetic in the steady state.  Out-of-range offsets return zeros (hardware bounds check), which is how
     // the implicit-GEMM zero padding (3x3 halo) is produced.
-    const int srow = lane >> 3, spos = lane & 7;
+    const int srow = lane / LPR, spos = lane % LPR;
+    // chunk swizzle of tile row r: 128-byte rows (r >> 1) & 7; 64-byte rows (-(r >> 2)) & 3 -- with either, the 16 lanes that one
+    // ds_read_b128 cycle serves ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md "LDS") hit 16 different 16-byte bank groups
+    auto swz = [](int r) { return KB == 64 ? (r >> 1) & 7 : (0 - (r >> 2)) & 3; };
+    const bool doA = !ROLES || wave < NWA, doB = !ROLES || wave >= NWA;   // wave-uniform
+    const int wa = ROLES ? (wave < NWA ? wave : 0) : wave, wb = ROLES ? (wave >= NWA ? wave - NWA : 0) : wave;
     constexpr uint32_t kOOB = 0x80000000u;
     uint32_t a_off[AI], a_off2[AI];   // byte offsets: linear: row*lda (+chunk) in a / a2; conv: centre tap pixel
     int a_mask[AI];                   // conv: bit t set <=> tap t (= ky*3+kx) of this row is inside the image
     int a_b[AI], a_y[AI], a_x[AI];    // conv + upsample only: coordinates for the per-tile gather
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-        const int rl = (wave * AI + j) * 8 + srow;
+        const int rl = (wa * AI + j) * RPI + srow;
         int m = m0 + rl;
-        const uint32_t ck = (uint32_t)(spos ^ ((rl >> 1) & 7)) * 16u;   // bytes
+        const uint32_t ck = (uint32_t)(spos ^ swz(rl)) * 16u;   // bytes
         const bool mvalid = m < p.M;
         if (!mvalid) m = p.M - 1;    // rows >= M are never stored: any in-range data will do
         a_off2[j] = 0; a_mask[j] = 0; a_b[j] = a_y[j] = a_x[j] = 0;
@@ -287,8 +329,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     uint32_t b_off[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-        const int rl = (wave * BI + j) * 8 + srow;
-        b_off[j] = (uint32_t)((int64_t)(n0 + rl) * p.ldw * 2) + (uint32_t)(spos ^ ((rl >> 1) & 7)) * 16u;
+        const int rl = (wb * BI + j) * RPI + srow;
+        b_off[j] = (uint32_t)((int64_t)(n0 + rl) * p.ldw * 2) + (uint32_t)(spos ^ swz(rl)) * 16u;
     }
     // conv: descriptor base = a - (Wi+1) pixels, so that tap (ky,kx) is the NON-NEGATIVE uniform offset
     // (ky*Wi + kx)*cin*2; the bytes in front of the tensor are never touched (those taps are masked)
@@ -299,16 +341,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     int kt0 = 0;  // first K-tile of this workgroup's K slice (set below)
     auto issue_tile = [&](int kt, int buf) {
         const int k0 = (kt0 + kt) * BK;
-        u16* as = As + buf * BM * BK + (wave * AI) * 8 * BK;
-        u16* bs = Bs + buf * BN * BK + (wave * BI) * 8 * BK;
-        if (CONV) {
+        u16* as = As + buf * BM * BK + (wa * AI) * RPI * BK;
+        u16* bs = Bs + buf * BN * BK + (wb * BI) * RPI * BK;
+        if (!doA) {
+        } else if (CONV) {
             const int tap = k0 / p.cin, c0 = k0 - tap * p.cin;
             const int ky = tap / 3, kx = tap - ky * 3;
             if (!p.upsample) {
                 const uint32_t soff = (uint32_t)(((ky * p.Wi + kx) * p.cin + c0) * 2);
 #pragma unroll
                 for (int j = 0; j < AI; ++j)
-                    buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? a_off[j] : kOOB, soff, as + j * 8 * BK);
+                    buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? a_off[j] : kOOB, soff, as + j * RPI * BK);
             } else {   // nearest upsample folded in (F.interpolate(mode="nearest") to Ho x Wo, then the conv): source pixel
                        // floor(v * Hi / Ho) -- v >> 1 for the usual x2 -- not affine in the tap
                 const bool x2 = p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi;
@@ -316,9 +359,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                 for (int j = 0; j < AI; ++j) {
                     const int vy = a_y[j] + ky - 1, vx = a_x[j] + kx - 1;
                     const int iy = x2 ? vy >> 1 : (vy > 0 ? vy * p.Hi / p.Ho : 0), ix = x2 ? vx >> 1 : (vx > 0 ? vx * p.Wi / p.Wo : 0);
-                    const uint32_t ck = (uint32_t)(spos ^ ((((wave * AI + j) * 8 + srow) >> 1) & 7)) * 16u;
+                    const uint32_t ck = (uint32_t)(spos ^ swz((wa * AI + j) * RPI + srow)) * 16u;
                     const uint32_t off = (uint32_t)((((int64_t)a_b[j] * p.Hi + iy + 1) * p.Wi + ix + 1) * p.cin * 2) + ck;
-                    buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? off : kOOB, (uint32_t)(c0 * 2), as + j * 8 * BK);
+                    buf_glds16(rs_a, ((a_mask[j] >> tap) & 1) ? off : kOOB, (uint32_t)(c0 * 2), as + j * RPI * BK);
                 }
             }
         } else {
@@ -326,14 +369,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             const uint32_t soff = (uint32_t)((first ? k0 : k0 - p.c1) * 2);
             if (first) {
 #pragma unroll
-                for (int j = 0; j < AI; ++j) buf_glds16(rs_a, a_off[j], soff, as + j * 8 * BK);
+                for (int j = 0; j < AI; ++j) buf_glds16(rs_a, a_off[j], soff, as + j * RPI * BK);
             } else {
 #pragma unroll
-                for (int j = 0; j < AI; ++j) buf_glds16(rs_a2, a_off2[j], soff, as + j * 8 * BK);
+                for (int j = 0; j < AI; ++j) buf_glds16(rs_a2, a_off2[j], soff, as + j * RPI * BK);
             }
         }
+        if (doB) {
 #pragma unroll
-        for (int j = 0; j < BI; ++j) buf_glds16(rs_w, b_off[j], (uint32_t)(k0 * 2), bs + j * 8 * BK);
+            for (int j = 0; j < BI; ++j) buf_glds16(rs_w, b_off[j], (uint32_t)(k0 * 2), bs + j * RPI * BK);
+        }
     };
 
     acc_t acc[FN][FM];
@@ -350,7 +395,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     if (!CONV && m0 + BM <= p.zero_rows) nkt = 0;   // the whole A tile is declared zero: epilogue only (bias + residual)
     // fragment reads: lane -> row (lane % F) of the fragment, 16-byte chunk (lane / F) of the k-step; (row>>1)&7 == (lane>>1)&7
     // because fragment rows are F-aligned (F = 16: ((lane & 15) >> 1) == (lane >> 1) & 7)
-    const int frow = lane & (F - 1), fsw = (lane >> 1) & 7, fhalf = lane >> LF;
+    const int frow = lane & (F - 1), fsw = swz(lane & (F - 1)), fhalf = lane >> LF;
     if constexpr (STAG) {
         static_assert(NW == 8 && D == 2, "staggered schedule: 8 waves, 3 stages");
         constexpr int PW = AI + BI;  // LDS-DMA instructions per wave per K-tile
@@ -395,51 +440,130 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
         if (!grpB) wait_lds_then_barrier();   // matches group B's leading barrier
-    } else {
-    #pragma unroll
-        for (int s = 0; s < D; ++s)
+    } else if constexpr (KB == 32) {
+        // four stages of 32: at the top of step kt the fragments of tile kt are in registers (read during step kt - 1), tile kt + 1
+        // has landed, tiles kt + 2 and kt + 3 are in flight; the barrier frees the stage of tile kt for tile kt + 4, whose DMA is
+        // issued first, then the fragment reads of tile kt + 1 (second register buffer), then the 30 MFMAs of tile kt cover both.
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s)
             if (s < nkt) issue_tile(s, s);
-        int cur = 0, nxt = D % STAGES;  // stage of tile kt / of tile kt+D
         PCDM_STAMP(1);
-        for (int kt = 0; kt < nkt; ++kt) {
-            // tile kt must have landed; up to D-1 younger tiles stay in flight across the barrier
-            const int pending = (nkt - 1 - kt) < (D - 1) ? (nkt - 1 - kt) : (D - 1);
-            if (D >= 3 && pending == 2) wait_vm_then_barrier<2 * (AI + BI)>();
-            else if (D >= 2 && pending == 1) wait_vm_then_barrier<AI + BI>();
-            else wait_vm_then_barrier<0>();
-            // every wave is past its reads of the stage tile kt+D goes to (it held tile kt-1)
-            if (kt == 0) PCDM_STAMP(2);
-            if (kt + D < nkt && !(p.debug & 1)) issue_tile(kt + D, nxt);
-            const u16* as = As + cur * BM * BK + (wm * WM + frow) * BK;
-            const u16* bs = Bs + cur * BN * BK + (wn * WN + frow) * BK;
+        u16x8 xf[2][FM], wf[2][FN];
+        const int co = (fhalf ^ fsw) * 8;
+        auto load_frags = [&](int stage, auto bsel) {
+            constexpr int b = decltype(bsel)::value;
+            const u16* as = As + stage * BM * BK + (wm * WM + frow) * BK + co;
+            const u16* bs = Bs + stage * BN * BK + (wn * WN + frow) * BK + co;
+#pragma unroll
+            for (int j = 0; j < FM; ++j) xf[b][j] = *(const u16x8*)(as + j * F * BK);
+#pragma unroll
+            for (int i = 0; i < FN; ++i) wf[b][i] = *(const u16x8*)(bs + i * F * BK);
+        };
+        auto wait_tiles = [&](int younger) {   // all but the `younger` most recent tiles of this wave have landed, then barrier
+            if (younger >= 3) wait_vm_lds_then_barrier<3 * PWT>();
+            else if (younger == 2) wait_vm_lds_then_barrier<2 * PWT>();
+            else if (younger == 1) wait_vm_lds_then_barrier<PWT>();
+            else wait_vm_lds_then_barrier<0>();
+        };
+        if (nkt > 0) {
+            wait_tiles(nkt - 1 < 3 ? nkt - 1 : 3);
+            PCDM_STAMP(2);
+            load_frags(0, std::integral_constant<int, 0>());
+        }
+        auto step = [&](int kt, auto bsel) {
+            constexpr int b = decltype(bsel)::value;
+            const int left = nkt - 2 - kt;       // tiles issued beyond kt + 1
+            wait_tiles(left < 0 ? 0 : (left < 2 ? left : 2));
+            if (kt + STAGES < nkt && !(p.debug & 1)) issue_tile(kt + STAGES, kt & 3);
+            if (kt + 1 < nkt) load_frags((kt + 1) & 3, std::integral_constant<int, b ^ 1>());
+            PCDM_SCHED_BARRIER();
             if (!(p.debug & 2)) {
-                // register double-buffered fragments: the ds_reads of k-step ks+1 are issued BEFORE the MFMAs of
-                // k-step ks (pinned with a scheduling barrier) so they get the whole MFMA window to return
-                u16x8 xf[2][FM], wf[2][FN];
-                auto load_frags = [&](int ks, int b) {
-                    const int co = ((ks * CPK + fhalf) ^ fsw) * 8;
-    #pragma unroll
-                    for (int j = 0; j < FM; ++j) xf[b][j] = *(const u16x8*)(as + j * F * BK + co);
-    #pragma unroll
-                    for (int i = 0; i < FN; ++i) wf[b][i] = *(const u16x8*)(bs + i * F * BK + co);
-                };
-                load_frags(0, 0);
-    #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    if (ks + 1 < NKS) load_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = mfma_16x16x32(wf[b][i], xf[b][j], acc[i][j]);
+            }
+            PCDM_SCHED_BARRIER();
+        };
+        for (int kt = 0; kt < nkt; kt += 2) {
+            step(kt, std::integral_constant<int, 0>());
+            if (kt + 1 < nkt) step(kt + 1, std::integral_constant<int, 1>());
+        }
+    } else {
+        // Rotated schedule: the workgroup barrier of a K-tile sits BEFORE the MFMAs of its last k-step, whose fragments are already in
+        // registers -- the matrix pipe has work the moment the barrier opens, and the fragment reads of the next tile's first k-step
+        // (issued right behind the barrier) return underneath it.  (With the barrier at the top of the tile every wave of the CU waited
+        // out a full LDS round trip per K-tile with the matrix pipe idle: the loop without any global loads ran at 1.15 PF/s.)
+        // At that barrier every wave has finished reading the stage of tile kt (all its k-steps are in registers or consumed), so the
+        // stage is refilled with tile kt + STAGES straight away: STAGES - 1 tiles in flight behind the one being multiplied.
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s)
+            if (s < nkt) issue_tile(s, s);
+        PCDM_STAMP(1);
+        u16x8 xf[2][FM], wf[2][FN];
+        auto load_frags = [&](int stage, int ks, auto bsel) {
+            constexpr int b = decltype(bsel)::value;
+            const int co = ((ks * CPK + fhalf) ^ fsw) * 8;
+            const u16* as = As + stage * BM * BK + (wm * WM + frow) * BK + co;
+            const u16* bs = Bs + stage * BN * BK + (wn * WN + frow) * BK + co;
+#pragma unroll
+            for (int j = 0; j < FM; ++j) xf[b][j] = *(const u16x8*)(as + j * F * BK);
+#pragma unroll
+            for (int i = 0; i < FN; ++i) wf[b][i] = *(const u16x8*)(bs + i * F * BK);
+        };
+        auto mfma_block = [&](auto bsel) {
+            constexpr int b = decltype(bsel)::value;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    if constexpr (F == 32) acc[i][j] = mfma_32x32x16(wf[b][i], xf[b][j], acc[i][j]);
+                    else acc[i][j] = mfma_16x16x32(wf[b][i], xf[b][j], acc[i][j]);
+                }
+        };
+        auto wait_landed = [&](int younger) {   // all but this wave's `younger` most recent tiles have landed + its ds_reads; barrier
+            if (STAGES >= 4 && younger >= 3) wait_vm_lds_then_barrier<3 * PWT>();
+            else if (STAGES >= 3 && younger == 2) wait_vm_lds_then_barrier<2 * PWT>();
+            else if (younger == 1) wait_vm_lds_then_barrier<PWT>();
+            else wait_vm_lds_then_barrier<0>();
+        };
+        typedef std::integral_constant<int, 0> B0;
+        typedef std::integral_constant<int, 1> B1;
+        static_assert(NKS % 2 == 0, "k-steps per K-tile");
+        if (nkt > 0) {
+            wait_landed(nkt - 1 < STAGES - 1 ? nkt - 1 : STAGES - 1);
+            PCDM_STAMP(2);
+            load_frags(0, 0, B0());
+        }
+        int cur = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+            for (int ks = 0; ks + 1 < NKS; ks += 2) {
+                // the buffer-0 fragments were requested a whole MFMA block ago: this wait is free, and with at most one block of
+                // reads outstanding the compiler's scoreboard stays exact (beyond 15 pending LDS operations it falls back to
+                // lgkmcnt(0) in front of the MFMAs, which serialises the reads it was meant to overlap)
+                wait_lds();
+                load_frags(cur, ks + 1, B1());
+                PCDM_SCHED_BARRIER();
+                mfma_block(B0());
+                PCDM_SCHED_BARRIER();
+                if (ks + 2 < NKS) {
+                    wait_lds();
+                    load_frags(cur, ks + 2, B0());
                     PCDM_SCHED_BARRIER();
-    #pragma unroll
-                    for (int i = 0; i < FN; ++i)
-    #pragma unroll
-                        for (int j = 0; j < FM; ++j) {
-                            if constexpr (F == 32) acc[i][j] = mfma_32x32x16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j]);
-                            else acc[i][j] = mfma_16x16x32(wf[ks & 1][i], xf[ks & 1][j], acc[i][j]);
-                        }
+                    mfma_block(B1());
                     PCDM_SCHED_BARRIER();
                 }
             }
-            cur = cur + 1 == STAGES ? 0 : cur + 1;
-            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+            const int left = nkt - 2 - kt;   // tiles issued beyond kt + 1
+            wait_landed(left < 0 ? 0 : (left < STAGES - 2 ? left : STAGES - 2));
+            if (kt + STAGES < nkt && !(p.debug & 1)) issue_tile(kt + STAGES, cur);
+            const int nx = cur + 1 == STAGES ? 0 : cur + 1;
+            if (kt + 1 < nkt) load_frags(nx, 0, B0());
+            PCDM_SCHED_BARRIER();
+            mfma_block(B1());
+            PCDM_SCHED_BARRIER();
+            cur = nx;
         }
     }
 
@@ -707,8 +831,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32, int KB = 64>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    constexpr int BK = KB;
     // operand ring, or the wave-private fp32 epilogue tiles (32 x (WN + 4) floats per wave) if those need more
     constexpr int smem_ops = STAGES * (BM + BN) * BK * (int)sizeof(u16);
     constexpr int FN_ = BN / WGN / F, CGM_ = 64 / F;
@@ -716,7 +841,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F>,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
@@ -725,7 +850,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     GemmArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = a.Npad / BN;
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F>), dim3(g.tiles_m * g.tiles_n * g.split_k),
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB>), dim3(g.tiles_m * g.tiles_n * g.split_k),
                 dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
     if (g.split_k > 1) {
@@ -782,6 +907,13 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         // (measured and dropped, never selected by the tuner: 128x320 / 4 waves; 96x320 / 4 waves of 96x80 with two or three stages;
         //  128x160 / 2 waves with three stages)
         case 26: return launch_gemm<192, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96x64 each: GEGLU-capable), 112 KiB
+        // (measured and dropped, never selected by the tuner: tile 21 / a 256x256 tile with FOUR stages of K = 32 -- three tiles in flight
+        //  in the same 128 KiB, template parameter KB = 32 -- 10-15 % slower: 64-byte rows double the cache-line requests per staged
+        //  byte, and the loop was not latency-bound in the first place: tools/ablate_gemm.py, profiles/r2_gemm_ablation.txt)
+#ifdef PCDM_DEV_KB32
+        case 27: return launch_gemm<192, 320, 2, 4, 4, CONV, false, 16, 32>(a, st);
+        case 28: return launch_gemm<256, 256, 2, 4, 4, CONV, false, 16, 32>(a, st);
+#endif
         default: return -1;
     }
 }

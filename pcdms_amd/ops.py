@@ -313,7 +313,7 @@ def _autotune(p: GemmParams, stream, pw: PackedWeight, epilogue: int, device, ou
 
 # ---- committed per-shape tuning table (measured on MI355X by tools/tune_gemm_shapes.py); shapes not in the table
 # are tuned online at first use.  Keys: "M,Npad,K,conv,stride,upsample,epilogue,two_source,residual".
-TUNING_FILE = Path(__file__).resolve().parent / "tuning" / "gfx950.json"
+TUNING_FILE = Path(os.environ.get("PCDM_TUNING_TABLE") or Path(__file__).resolve().parent / "tuning" / "gfx950.json")   # (env: A/B runs)
 
 
 def load_tuning(path: Path = TUNING_FILE) -> int:

@@ -488,7 +488,7 @@ def test_gemm_full_row_tiles_and_zero_rows(backend):
     ``zero_rows`` (A rows declared all-zero: not read, tiles entirely inside run the epilogue only) on old and new tiles."""
     dev = backend.device
     tiles = (21,)
-    M, K, N = (300, 128, 320) if backend.is_emu else (5632 * 2 + 100, 640, 640)
+    M, K, N = (300, 192, 320) if backend.is_emu else (5632 * 2 + 100, 640, 640)
     a = rnd(M, K, seed=60)
     w = rnd(N, K, seed=61, scale=1 / math.sqrt(K))
     bias = torch.randn(N, generator=torch.Generator().manual_seed(62))
@@ -519,7 +519,7 @@ def test_gemm_full_row_tiles_and_zero_rows(backend):
         a2, w2 = rnd(704, 11520, seed=65), rnd(1280, 11520, seed=66, scale=1 / math.sqrt(11520))
         pw2 = ops.pack_linear(w2.float(), None, dev)
         out = torch.empty(704, 1280, dtype=BF16, device=dev)
-        for tile, sk in ((21, 4), (26, 3)):
+        for tile, sk in ((21, 4), (21, 7), (26, 3)):
             ops.gemm(a2.to(dev), pw2, out, tile=tile, split_k=sk)
             backend.sync()
             close(out, a2.float() @ w2.float().t())

@@ -16,7 +16,7 @@ from pcdms_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.lib()
 BF16 = torch.bfloat16
-NW = {21: 8, 19: 8, 18: 8, 3: 8, 13: 4, 4: 4, 22: 4, 25: 4, 26: 8, 17: 8, 1: 8}
+NW = {21: 8, 19: 8, 18: 8, 3: 8, 13: 4, 4: 4, 22: 4, 25: 4, 26: 8, 17: 8, 1: 8, 4: 4}
 
 
 def run(M, N, K, tile, residual=True, reps=3):
@@ -65,8 +65,9 @@ def run(M, N, K, tile, residual=True, reps=3):
 
 
 if __name__ == "__main__":
-    for (M, N, K) in [(45056, 320, 320), (45056, 960, 320), (45056, 320, 1280), (11264, 640, 640), (2816, 1280, 1280)]:
-        for tile in (21, 19, 18, 13):
+    # thin-K linears (the prologue / epilogue share) and deep-K problems (the per-K-tile cost of the loop: main loop / (K / 64))
+    for (M, N, K) in [(45056, 320, 320), (45056, 960, 320), (45056, 320, 1280), (45056, 320, 5760), (11264, 1280, 5760), (11264, 640, 640)]:
+        for tile in (21, 17, 4):
             if (N % ops.TILE_SHAPES[tile][1]) == 0:
-                for res in (True, False):
+                for res in ((True, False) if K <= 1280 else (False,)):
                     run(M, N, K, tile, res)
