@@ -30,7 +30,9 @@ int pcdm_is_emulator(void);
  *      conv_norm_out: stage2_inpaint_unet_2d_condition.py:435-441,817-819].
  * x = virtual channel-concat of x1 [B,HW,C1] and x2 [B,HW,C2] (x2 may be NULL, C2 = 0): the up-block
  * skip concat (ref :792-793, K6) is never materialised.  y [B,HW,C1+C2] bf16.
- * ws: fp32 workspace of pcdm_groupnorm_ws_floats(B, C1+C2) floats. */
+ * ws: fp32 workspace of pcdm_groupnorm_ws_floats(B, C1+C2) floats, ZERO-FILLED once when allocated and written by nothing but
+ * pcdm_groupnorm afterwards (its head holds arrival counters that every launch leaves at zero); one workspace may serve calls of
+ * any shape with B' <= B on one stream. */
 int64_t pcdm_groupnorm_ws_floats(int B, int C);
 int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
                    const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);

@@ -7,6 +7,7 @@ tests can inject the lane-emulator build of the *same sources*; the product neve
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
@@ -16,7 +17,7 @@ from typing import Optional
 import torch  # noqa: F401
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libpcdm.so"
+LIB_PATH = Path(os.environ.get("PCDM_LIB") or _HERE / "lib" / "libpcdm.so")   # (env: another build of the SAME library, for same-box A/B runs)
 
 _lib: Optional[C.CDLL] = None
 _is_emu = False

@@ -322,8 +322,8 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict
 
 // ---- single-pass GroupNorm for slabs that do NOT fit one workgroup (UNet level 0: 5632 rows; level 1 at C = 640 with only 128
 // slabs): the rows of a (batch, group set) slab are split over S workgroups that each keep their chunk in registers, publish their
-// per-group {sum, sum of squares} and wait for the other S - 1 (agent-scope write-through stores -> drained -> ticket; relaxed poll ->
-// agent-scope loads: cdna_hip_programming.md Guideline 16, the fence-free form), then every workgroup finishes the statistics itself (fixed chunk order, fp64: bit-identical
+// per-group {sum, sum of squares} and wait for the other S - 1 (system-scope write-through stores -> drained -> ticket; relaxed poll ->
+// system-scope loads: cdna_hip_programming.md Guideline 16, the fence-free form), then every workgroup finishes the statistics itself (fixed chunk order, fp64: bit-identical
 // in all of them and run to run) and normalises its rows: 2 bytes moved per element and ONE launch, where the two-kernel path moves 3
 // in two launches.  The grid is at most one workgroup per CU, so all S partners are resident (no deadlock); the counters are
 // self-resetting (the last workgroup to have READ the partials clears them; the next launch cannot start before this one ends).
@@ -399,22 +399,23 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
     // ---- publish, wait for the partners, finish the statistics
     float* part = ws + (int64_t)slab * S * 8;
-    unsigned* cnt = (unsigned*)(ws + (int64_t)nslab * S * 8) + slab * 2;
-    // (payload and counter both by agent-scope accesses -- write-through stores drained before the ticket, L2-bypassing loads after
-    //  the poll: no release / acquire FENCE, whose L2 write-back of the previous kernel's still-dirty output cost ~7 us per launch here)
-    if (t < 8) pcdm_store_agent(part + chunk * 8 + t, (t & 1) ? qg[t >> 1] : sg[t >> 1]);
+    unsigned* cnt = (unsigned*)(ws + kGnClusterMaxWgs * 8) + slab * 2;   // fixed offset, whatever the grid (see pcdm_groupnorm_ws_floats)
+    // (payload by SYSTEM-scope accesses -- write-through stores drained before the ticket, loads served by memory after the poll: no
+    //  release / acquire FENCE, whose L2 write-back of the previous kernel's still-dirty output cost ~7 us per launch here.  Agent
+    //  scope is NOT enough for the loads: see pcdm_load_sys.)
+    if (t < 8) pcdm_store_sys(part + chunk * 8 + t, (t & 1) ? qg[t >> 1] : sg[t >> 1]);
     pcdm_drain_vmem();
     __syncthreads();
     if (t == 0) {
         pcdm_atomic_inc_agent(cnt);
-        while (pcdm_load_agent_u32(cnt) < (unsigned)S) pcdm_sleep();
+        while (pcdm_load_sys_u32(cnt) < (unsigned)S) pcdm_sleep();
     }
     __syncthreads();
     if (t < gpb) {
         double ss = 0.0, qq = 0.0;
         for (int ch = 0; ch < S; ++ch) {
-            ss += (double)pcdm_load_agent(part + ch * 8 + 2 * t);
-            qq += (double)pcdm_load_agent(part + ch * 8 + 2 * t + 1);
+            ss += (double)pcdm_load_sys(part + ch * 8 + 2 * t);
+            qq += (double)pcdm_load_sys(part + ch * 8 + 2 * t + 1);
         }
         const double mean = ss * inv_n;            // (fp64 multiplies only: fp64 divide / sqrt sequences cost ~40 registers here)
         double var = qq * inv_n - mean * mean;
@@ -425,8 +426,8 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     __syncthreads();
     if (t == 0) {   // the partials have been read: the last reader re-arms the counters for the next launch
         if (pcdm_atomic_inc_agent(cnt + 1) == (unsigned)S - 1) {
-            pcdm_store_agent_u32(cnt, 0u);
-            pcdm_store_agent_u32(cnt + 1, 0u);
+            pcdm_store_sys_u32(cnt, 0u);
+            pcdm_store_sys_u32(cnt + 1, 0u);
         }
     }
     if (!active) return;
@@ -599,9 +600,18 @@ static bool gn_cluster_enabled() {
 #endif
 }
 
+static int64_t gn_ws_stats_floats(int B) { return (int64_t)B * kGnMaxChunks * 256 * 2; }
+constexpr int kGnClusterFloats = kGnClusterMaxWgs * 8 + kGnClusterMaxWgs * 2;   // head of the workspace
+
 extern "C" int64_t pcdm_groupnorm_ws_floats(int B, int C) {
     (void)C;
-    return (int64_t)B * kGnMaxChunks * 256 * 2;   // [B][chunks][groups <= 256][2]
+    // cluster kernel: 8 floats per workgroup, then its arrival counters (2 per slab) | [B][chunks][groups <= 256][2] partial statistics
+    // of the two-kernel path.  The counters have a region of their OWN at a FIXED offset (not a function of B or of the grid: one
+    // workspace serves calls of every shape): nothing else may ever write there (they are
+    // zero when the workspace is allocated and every cluster launch leaves them zero) -- when they shared the area with the partial
+    // statistics, a launch of another shape left float bit patterns in them, the poll fell through at once and the partners' sums were
+    // read before they were written (2-4 % run-to-run differences in the full-size UNet forward).
+    return kGnClusterFloats + gn_ws_stats_floats(B);
 }
 
 extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
@@ -652,15 +662,16 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
             for (int S = 2; S <= 8 && nslab * S <= kGnClusterMaxWgs; S *= 2) {
                 const int rpc = (HW + S - 1) / S;
                 const int need = (rpc + rows_par - 1) / rows_par;
-                if (need > 16 || (int64_t)nslab * (S * 8 + 2) > pcdm_groupnorm_ws_floats(B, C)) continue;
+                if (need > 16) continue;
+                float* cws = ws;   // cluster area at the head of the workspace: [kGnClusterMaxWgs][8] partials, then the counters
                 const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
                 const double inv_n = 1.0 / ((double)HW * gs);
                 if (need <= 8)
                     PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, 8>), dim3(nslab * S), dim3(512), 0, st, a1, C1, a2, C2, B, HW, gs, gpb,
-                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, ws);
+                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, cws);
                 else
                     PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, 16>), dim3(nslab * S), dim3(512), 0, st, a1, C1, a2, C2, B, HW, gs, gpb,
-                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, ws);
+                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, cws);
                 PCDM_CHECK_LAUNCH();
                 return 0;
             }
@@ -670,6 +681,7 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
     const GnGeom g = gn_geom(C);
     const int nchunk = gn_chunks(HW, g.rows_par);
     const int rpc = (HW + nchunk - 1) / nchunk;
+    ws += kGnClusterFloats;   // (the head belongs to the cluster kernel)
     PCDM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, (const u16*)x1, C1, (const u16*)x2, C2, HW,
                 rpc, groups, ws);
     PCDM_CHECK_LAUNCH();

@@ -288,6 +288,10 @@ __device__ __forceinline__ float pcdm_load_agent(const float* p) { return *p; }
 __device__ __forceinline__ void pcdm_store_agent(float* p, float v) { *p = v; }
 __device__ __forceinline__ unsigned pcdm_load_agent_u32(const unsigned* p) { return *(volatile const unsigned*)p; }
 __device__ __forceinline__ void pcdm_store_agent_u32(unsigned* p, unsigned v) { *p = v; }
+__device__ __forceinline__ void pcdm_store_sys(float* p, float v) { *p = v; }
+__device__ __forceinline__ float pcdm_load_sys(const float* p) { return *p; }
+__device__ __forceinline__ unsigned pcdm_load_sys_u32(const unsigned* p) { return *(volatile const unsigned*)p; }
+__device__ __forceinline__ void pcdm_store_sys_u32(unsigned* p, unsigned v) { *p = v; }
 __device__ __forceinline__ void pcdm_sleep() {}
 #else
 __device__ __forceinline__ void pcdm_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -310,6 +314,18 @@ __device__ __forceinline__ unsigned pcdm_load_agent_u32(const unsigned* p) {
 }
 __device__ __forceinline__ void pcdm_store_agent_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// SYSTEM scope (sc0 sc1): the load is served by memory, not by this XCD's L2.  An agent-scope (sc1) load bypasses only the CU's L1: a
+// line that this XCD's L2 still holds from an EARLIER kernel's read of the same address is returned stale when another XCD has
+// since written it through -- seen as run-to-run differences of 2-4 % in the full-size UNet forward, invisible in any test that
+// streams >= 4 MB per XCD between two launches (cdna_hip_programming.md G16: "sc0 sc1 stores AND loads, both sides")
+__device__ __forceinline__ void pcdm_store_sys(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float pcdm_load_sys(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned pcdm_load_sys_u32(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void pcdm_store_sys_u32(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void pcdm_sleep() { __builtin_amdgcn_s_sleep(2); }
 #endif

@@ -88,30 +88,62 @@ def test_layernorm(backend):
 @pytest.mark.gpu
 def test_groupnorm_cluster_rearm_and_determinism(gpu_backend):
     """The cluster GroupNorm (a slab split over S workgroups that exchange partial statistics through global memory and wait for
-    each other) over many back-to-back launches that share ONE workspace: alternating shapes / cluster sizes, every result
-    bit-identical to the first of its shape and equal to the reference -- the counters re-arm, no stale partials are ever read, and
-    the launch never hangs (pytest-timeout would kill it)."""
+    each other) over many back-to-back launches that share ONE workspace with each other AND with the two-kernel path: alternating
+    shapes / cluster sizes / grids, differently scaled data every time; every result equal to the reference and bit-identical to the
+    first of its (shape, scale) -- the counters re-arm, nothing else ever writes them (round 2: they once shared the area with the
+    other launches' partial statistics and the poll fell through), no stale partials are read, and the launch never hangs
+    (pytest-timeout would kill it)."""
     dev = gpu_backend.device
-    shapes = [(8, 64 * 88, 320, 32), (8, 32 * 44, 640, 32), (4, 64 * 88, 320, 32), (8, 32 * 44, 320, 32)]
+    # cluster: grids 256, 256, 128, 128; two-kernel path: (8, 5632, 960) and (3, 5632, 640)
+    shapes = [(8, 64 * 88, 320, 32), (8, 32 * 44, 640, 32), (4, 64 * 88, 320, 32), (8, 32 * 44, 320, 32), (8, 64 * 88, 960, 32),
+              (3, 64 * 88, 640, 32)]
     ws = ops.groupnorm_ws(16, 4096, dev)
     data, first = {}, {}
     for i, (B, HW, C, G) in enumerate(shapes):
-        x = (rnd(B * HW, C, seed=90 + i) * (1 + i) + 0.3 * i).to(dev)
+        x = rnd(B * HW, C, seed=90 + i)
         gamma = (torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5).to(dev)
         beta = (torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2).to(dev)
-        data[i] = (x, gamma, beta, torch.empty(B * HW, C, dtype=BF16, device=dev))
-    for it in range(40):
+        data[i] = (x, gamma, beta)
+    for it in range(48):
         i = (it * 7 + it // 3) % len(shapes)
+        k = (it // 2) % 3                        # scale / shift of this launch's data
         B, HW, C, G = shapes[i]
-        x, gamma, beta, out = data[i]
-        out.fill_(float("nan"))
+        x0, gamma, beta = data[i]
+        x = (x0.float() * (1.0 + 1.5 * k) + 2.0 * k - 1.0).to(BF16).to(dev)
+        out = torch.full((B * HW, C), float("nan"), dtype=BF16, device=dev)
         ops.groupnorm(x, None, B, HW, G, 1e-5, gamma, beta, True, out, ws)
-        if i in first:
-            assert torch.equal(out, first[i]), (it, i)
+        if (i, k) in first:
+            assert torch.equal(out, first[i, k]), (it, i, k)
         else:
-            first[i] = out.clone()
+            first[i, k] = out.clone()
             ref = F.silu(F.group_norm(x.float().cpu().view(B, HW, C).permute(0, 2, 1), G, gamma.cpu(), beta.cpu(), 1e-5))
             close(out.view(B, HW, C), ref.permute(0, 2, 1))
+
+
+@pytest.mark.gpu
+def test_groupnorm_cluster_no_stale_partials_back_to_back(gpu_backend):
+    """Cluster GroupNorm launches enqueued BACK TO BACK on one workspace, each with differently distributed data, nothing in between
+    to flush the L2s: the partial statistics a workgroup reads must be the ones its partners wrote in THIS launch.  (With agent-scope
+    loads a partner's write-through was invisible to an XCD whose L2 still held the line from the previous launch's read: the
+    full-size UNet forward moved by 2-4 % from run to run while every test that synchronised between launches passed.)"""
+    dev = gpu_backend.device
+    B, HW, C, G = 2, 32 * 44, 320, 32           # 16 slabs x S = 2..8 workgroups: small enough that its own traffic leaves the L2s alone
+    ws = ops.groupnorm_ws(16, 4096, dev)
+    gamma = (torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2).to(dev)
+    n = 24
+    xs = [(rnd(B * HW, C, seed=200 + i) * (1.0 + 0.7 * (i % 5)) + 1.5 * ((i * 3) % 7 - 3)).to(dev) for i in range(n)]
+    outs = [torch.empty(B * HW, C, dtype=BF16, device=dev) for _ in range(n)]
+    for rep in range(3):
+        for o in outs:
+            o.fill_(float("nan"))
+        torch.cuda.synchronize()
+        for x, o in zip(xs, outs):               # enqueue only
+            ops.groupnorm(x, None, B, HW, G, 1e-5, gamma, beta, True, o, ws)
+        torch.cuda.synchronize()
+        for i, (x, o) in enumerate(zip(xs, outs)):
+            ref = F.silu(F.group_norm(x.float().cpu().view(B, HW, C).permute(0, 2, 1), G, gamma.cpu(), beta.cpu(), 1e-5))
+            close(o.view(B, HW, C), ref.permute(0, 2, 1))
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
