@@ -106,7 +106,7 @@ int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, cons
 /* The same with the lazy-rescale threshold made explicit: the running softmax reference of a query moves only when a key tile's
  * maximum exceeds it by more than thr_log2 (log2 units, 0 <= thr <= 16; P <= 2^thr); 0 = eager online softmax.  pcdm_flash_attn
  * uses PCDM_ATTN_DEFAULT_THR.  Mathematically identical for every thr (P, the row sum and O carry the same reference). */
-#define PCDM_ATTN_DEFAULT_THR 5.0f
+#define PCDM_ATTN_DEFAULT_THR 8.0f
 int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                         void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s);
 

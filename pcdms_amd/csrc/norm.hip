@@ -402,7 +402,7 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     unsigned* cnt = (unsigned*)(ws + kGnClusterMaxWgs * 8) + slab * 2;   // fixed offset, whatever the grid (see pcdm_groupnorm_ws_floats)
     // (payload by SYSTEM-scope accesses -- write-through stores drained before the ticket, loads served by memory after the poll: no
     //  release / acquire FENCE, whose L2 write-back of the previous kernel's still-dirty output cost ~7 us per launch here.  Agent
-    //  scope is NOT enough for the loads: see pcdm_load_sys.)
+    //  scope is not enough for the loads across XCDs: see pcdm_load_sys.)
     if (t < 8) pcdm_store_sys(part + chunk * 8 + t, (t & 1) ? qg[t >> 1] : sg[t >> 1]);
     pcdm_drain_vmem();
     __syncthreads();

@@ -315,10 +315,10 @@ __device__ __forceinline__ unsigned pcdm_load_agent_u32(const unsigned* p) {
 __device__ __forceinline__ void pcdm_store_agent_u32(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// SYSTEM scope (sc0 sc1): the load is served by memory, not by this XCD's L2.  An agent-scope (sc1) load bypasses only the CU's L1: a
-// line that this XCD's L2 still holds from an EARLIER kernel's read of the same address is returned stale when another XCD has
-// since written it through -- seen as run-to-run differences of 2-4 % in the full-size UNet forward, invisible in any test that
-// streams >= 4 MB per XCD between two launches (cdna_hip_programming.md G16: "sc0 sc1 stores AND loads, both sides")
+// SYSTEM scope (sc0 sc1) on both sides of a cross-workgroup hand-off without fences: the store is written through, the load is
+// served by memory, not by this XCD's L2.  An agent-scope (sc1) load bypasses only the CU's L1, and the per-XCD L2s are not coherent
+// with each other: a line this XCD's L2 still holds from an earlier read of the same address may be returned after another XCD has
+// written it (cdna_hip_programming.md G16 lists "sc0 sc1 stores AND loads, both sides" as the fence-free form that is valid).
 __device__ __forceinline__ void pcdm_store_sys(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ float pcdm_load_sys(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ unsigned pcdm_load_sys_u32(const unsigned* p) {

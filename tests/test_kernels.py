@@ -123,9 +123,9 @@ def test_groupnorm_cluster_rearm_and_determinism(gpu_backend):
 @pytest.mark.gpu
 def test_groupnorm_cluster_no_stale_partials_back_to_back(gpu_backend):
     """Cluster GroupNorm launches enqueued BACK TO BACK on one workspace, each with differently distributed data, nothing in between
-    to flush the L2s: the partial statistics a workgroup reads must be the ones its partners wrote in THIS launch.  (With agent-scope
-    loads a partner's write-through was invisible to an XCD whose L2 still held the line from the previous launch's read: the
-    full-size UNet forward moved by 2-4 % from run to run while every test that synchronised between launches passed.)"""
+    to flush the L2s: the partial statistics a workgroup reads must be the ones its partners wrote in THIS launch (the hand-off uses
+    system-scope stores / loads and no fences; the per-XCD L2s are not coherent with each other, and the same workspace lines are
+    re-read launch after launch)."""
     dev = gpu_backend.device
     B, HW, C, G = 2, 32 * 44, 320, 32           # 16 slabs x S = 2..8 workgroups: small enough that its own traffic leaves the L2s alone
     ws = ops.groupnorm_ws(16, 4096, dev)
