@@ -1,5 +1,5 @@
-"""bench.py output contract: the committed round-1 bench line (profiles/r1_bench.json, produced on an MI355X by `python bench.py`)
-carries every field the driver parses, and bench.py's flags / defaults are the ones the driver passes."""
+"""bench.py output contract: the committed bench lines (profiles/r1_bench.json, profiles/r2_bench.json, produced on an MI355X by
+`python bench.py`) carry every field the driver parses, and bench.py's flags / defaults are the ones the driver passes."""
 from __future__ import annotations
 
 import json
@@ -9,8 +9,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    line = (ROOT / "profiles" / "r1_bench.json").read_text().strip().splitlines()[-1]
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    line = (ROOT / "profiles" / name).read_text().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.loads((ROOT / "BASELINE.json").read_text())
     assert d["metric"].startswith("images/sec") and d["unit"] == "images/s" and base["metric"].startswith("images/sec")
@@ -29,6 +33,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r["achieved"] - r["alg_gflop_per_launch"] / r["avg_launch_us"] * 1e3)   # GFLOP / us = 1000 TFLOP/s < 0.02 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    if name.startswith("r2"):   # round 2: whole-path fraction, the RCCL world size, the full configs[0] CPU run
+        assert 0 < r["e2e_frac"] < 1 and cfg["rccl_world_size"] == d["n_gpus"] and c["config1"]["seconds"] > 0
 
 
 def test_bench_flags_and_defaults():
