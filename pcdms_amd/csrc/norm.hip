@@ -595,7 +595,16 @@ static bool gn_cluster_enabled() {
 #ifdef PCDM_EMU
     return false;
 #else
-    static const bool enabled = [] { const char* e = getenv("PCDM_GN_CLUSTER"); return !(e && e[0] == '0'); }();   // A/B switch
+    // The partners of a cluster wait for each other inside the launch: every workgroup of the grid must be resident at once.  One
+    // 512-thread workgroup per CU always fits, so the condition is a device with at least kGnClusterMaxWgs CUs (a full MI355X has
+    // 256; a partitioned one -- CPX mode -- does not, and takes the other paths).  PCDM_GN_CLUSTER=0: A/B switch.
+    static const bool enabled = [] {
+        const char* e = getenv("PCDM_GN_CLUSTER");
+        if (e && e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= kGnClusterMaxWgs;
+    }();
     return enabled;
 #endif
 }

@@ -19,25 +19,29 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
+    ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache before every timed launch (weights are never cached "
+                    "inside the real step)")
+    ap.add_argument("--only-main", action="store_true", help="only the bench configuration (UNet batch 8, latent 64x88)")
     args = ap.parse_args()
     from oracle.unet import UNetConfig, synth_state_dict
     from pcdms_amd import ops
     from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
     from tests.test_unet import _inputs, _kwargs
     ops._TUNED.clear()
-    ops.TUNE_ITERS, ops.TUNE_REPEATS = 5, 3
+    ops.TUNE_ITERS, ops.TUNE_REPEATS, ops.TUNE_COLD = 5, 3, args.cold
     dev = torch.device("cuda:0")
     cfg = UNetConfig()
     m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
     m.load_state_dict(synth_state_dict(cfg, seed=0))
     m.to(dev)
-    for (B, h, w) in [(8, 64, 88), (16, 64, 88), (2, 32, 64), (8, 32, 64)]:
+    for (B, h, w) in [(8, 64, 88)] if args.only_main else [(8, 64, 88), (16, 64, 88), (2, 32, 64), (8, 32, 64)]:
         s, e, c, p = _inputs(cfg, B, h, w, 258)
         m(s.to(dev), torch.tensor(500, device=dev), e.to(dev), class_labels=c.to(dev), my_pose_cond=p.to(dev))
         torch.cuda.synchronize()
         print(f"B={B} latent {h}x{w}: {len(ops._TUNED)} shapes tuned", flush=True)
     out = Path(args.out) if args.out else ops.TUNING_FILE
-    ops.save_tuning(out, note=f"MI355X gfx950, torch {torch.__version__}, tools/tune_gemm_shapes.py, best of 3 x 5 launches")
+    ops.save_tuning(out, note=f"MI355X gfx950, torch {torch.__version__}, tools/tune_gemm_shapes.py, best of 3 x 5 launches"
+                                + (", caches evicted before every timed launch" if args.cold else ""))
     print("wrote", out)
 
 
