@@ -400,6 +400,8 @@ extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, i
 
 // A/B switch of the row-sum path (tools/bench_attn.py; PCDM_ATTN_ROWSUM=valu|mfma in the environment at load time)
 static bool g_rowsum_valu = [] { const char* e = getenv("PCDM_ATTN_ROWSUM"); return e && e[0] == 'v'; }();
+// extra dynamic LDS per workgroup: an occupancy knob for experiments (e.g. 50000 -> 2 workgroups per CU instead of 3)
+static int g_lds_pad = [] { const char* e = getenv("PCDM_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
 
 extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                    void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s) {
@@ -409,7 +411,7 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
 #define PCDM_ATTN_LAUNCH(RS)                                                                                                            \
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
                 (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2)
     if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true);
     else PCDM_ATTN_LAUNCH(false);
