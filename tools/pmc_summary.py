@@ -4,8 +4,9 @@ the ratios that say where the wave cycles go (MI355X_MICROARCH.md "rocprofv3 PMC
 ~ WAVE_CYCLES, in quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles = 32 x MFMAs for 32x32x16, 16 x for 16x16x32).
 
     python tools/pmc_summary.py <dir-of-pass-a> <dir-of-pass-b> ... [--match flash_attn] > profiles/r2_pmc_*.json
-MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES): SQ_BUSY_CYCLES is summed over the SQs (one per CU ...
-calibrated on the MFMA-only microbenchmark it reads ~1.0), so the ratio is the share of SIMD-cycles with the matrix pipe busy."""
+MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) / (dispatch duration x 1024 SIMDs x clock); the
+duration comes from the dispatch's own Start / End timestamps in the counter CSV (serialised dispatches), the clock is taken as the
+2.4 GHz maximum, so the figure is a LOWER bound (under MFMA load the chip runs at 1.9-2.1 GHz: divide by ~0.85)."""
 from __future__ import annotations
 
 import csv
@@ -34,6 +35,8 @@ def main():
                 if match and match not in r["Kernel_Name"]:
                     continue
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if "Start_Timestamp" in r and "End_Timestamp" in r and r["Counter_Name"] == "SQ_WAVE_CYCLES":
+                    acc[short(r["Kernel_Name"])]["duration_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     out = {}
     for k, cs in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
         m = {c: sum(v) / len(v) for c, v in cs.items()}
@@ -44,8 +47,8 @@ def main():
                            ("SQ_ACTIVE_INST_ANY", "frac_wave_cycles_issuing"), ("SQ_WAIT_INST_LDS", "frac_wave_cycles_lds_issue_stalled")):
                 if c in m:
                     row[lbl] = round(m[c] / wc, 3)
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"]:
-            row["mfma_busy_frac (MFMA_BUSY / 4 / SQ_BUSY)"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / 4.0 / m["SQ_BUSY_CYCLES"], 3)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("duration_ns"):
+            row["mfma_busy_frac (>=, at 2.4 GHz)"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["duration_ns"] * 2.4 * 1024), 3)
         if "SQ_INSTS_MFMA" in m and m["SQ_INSTS_MFMA"]:
             for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
                 if c in m:

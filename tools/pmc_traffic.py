@@ -18,7 +18,7 @@ import sys
 
 
 def family(name: str) -> str:
-    for key, fam in (("gemm_kernel", "gemm_kernel"), ("flash_attn", "flash_attn_kernel"), ("gn_fused", "groupnorm (single pass)"),
+    for key, fam in (("gemm_kernel", "gemm_kernel"), ("flash_attn", "flash_attn_kernel"), ("gn_fused", "groupnorm (single pass)"), ("gn_cluster", "groupnorm (cluster single pass)"),
                      ("gn_stats", "groupnorm (stats pass)"), ("gn_apply", "groupnorm (apply pass)"), ("layernorm", "layernorm"),
                      ("splitk_reduce", "splitk_reduce")):
         if key in name:
