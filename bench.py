@@ -320,8 +320,8 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
 def cpu_baseline(sd, cfg, inp, N, ddim_steps):
     """The fp32 PyTorch CPU restatement (oracle/) timed on this box's host cores.  Substitute for the reference's CPU diffusers
     path, which cannot run (diffusers is not installed / vendored).  Two records:
-      * ``value``: configs[1] on a bounded sample -- 1 warm-up + 1 timed denoise step (UNet batch 2N at the full latent size +
-        CFG + DDIM update), extrapolated to the 50-step call;
+      * ``value``: configs[1] on a bounded sample -- 1 timed denoise step (UNet batch 2N at the full latent size + CFG + DDIM
+        update; the configs[0] run before it serves as warm-up), extrapolated to the 50-step call;
       * ``config1``: BASELINE.json configs[0] in FULL -- one 256x256 pair (canvas 512x256, latent 32x64), N = 1, 20 DDIM steps,
         guidance 2.0, fp32: wall seconds of the whole sampling loop (SURVEY.md §8d "config 1")."""
     from oracle.pipeline import build_conditioning, stage2_sample, synth_inputs
@@ -332,24 +332,23 @@ def cpu_baseline(sd, cfg, inp, N, ddim_steps):
     sch = DDIMOracle()
     sch.set_timesteps(ddim_steps)
     lat = inp["latents"].clone()
-    times = []
     with torch.no_grad():
-        for i, t in enumerate(sch.timesteps[:2]):
-            t0 = time.perf_counter()
-            x = torch.cat([lat] * 2)
-            eps = unet_forward(sd, cfg, torch.cat([x, c["mask"], c["masked_latents"]], 1), t, c["feature_f"],
-                               c["prior_embed"], c["pose_cond"])
-            u, cn = eps.chunk(2)
-            lat = sch.step(u + 2.0 * (cn - u), t, lat)
-            times.append(time.perf_counter() - t0)
-        per_step = times[-1]
+        # configs[0] first: it also warms the host thread pool / primitive caches for the full-size step that follows
         inp1 = synth_inputs(cfg, 32, 64, 1)
         t0 = time.perf_counter()
         out1 = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=1, guidance_scale=2.0, num_inference_steps=20, **inp1)
         c1_s = time.perf_counter() - t0
+        t = sch.timesteps[0]
+        t0 = time.perf_counter()
+        x = torch.cat([lat] * 2)
+        eps = unet_forward(sd, cfg, torch.cat([x, c["mask"], c["masked_latents"]], 1), t, c["feature_f"],
+                           c["prior_embed"], c["pose_cond"])
+        u, cn = eps.chunk(2)
+        lat = sch.step(u + 2.0 * (cn - u), t, lat)
+        per_step = time.perf_counter() - t0
     assert torch.isfinite(out1).all()
     return {"value": round(N / (per_step * ddim_steps), 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 timed denoise step (after 1 warm-up) of the same workload (UNet batch {2 * N}, fp32, "
+            "sample": f"1 timed denoise step (after the configs[0] run as warm-up) of the same workload (UNet batch {2 * N}, fp32, "
                       f"torch {torch.__version__} CPU ops), {per_step:.2f} s/step, extrapolated x{ddim_steps}",
             "config1": {"workload": "configs[0]: 1 pair 256x256 (latent 32x64), N=1, 20 DDIM steps, guidance 2.0, fp32 CPU, full run",
                         "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}
