@@ -1,26 +1,27 @@
 // bf16 MFMA GEMM / implicit-GEMM 3x3 convolution with fused epilogues (SURVEY.md §2.1 K1-K3,K5-K7,K11).
 //
-//   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),  fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+//   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),  fp32 accumulation on v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16.
 //
 // Design (gfx950):
-//  * One workgroup = 8 waves (4x2; block tile 256x128 or 256x64) or 4 waves (2x2; 128x128, 64x64), BK = 64.
-//    Each wave owns a 64x64 / 64x32 / 32x32 sub-tile as 32x32 MFMA fragments.  The MFMA is issued "swapped" -- D = Wfrag * Xfrag^T,
-//    rows = output channel n, cols = pixel/token m -- so that every lane ends up with 4 CONSECUTIVE
-//    output channels of one row in each accumulator quad: the epilogue adds bias / time-embedding /
-//    residual and stores 8-byte packed bf16 without any cross-lane traffic.
-//  * A (activations, NHWC bf16) and W (packed [N][K], K contiguous) tiles go HBM/L2 -> LDS by LDS-DMA
-//    (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip) into a ring of STAGES LDS buffers: tiles
-//    t+1 .. t+STAGES-1 are in flight while the MFMAs of tile t run; ONE raw s_barrier per K-tile preceded by
-//    a COUNTED s_waitcnt vmcnt(N) so the younger tiles' DMAs stay in flight across it (the loop is L2-latency
-//    bound otherwise: one 32 KiB tile in flight per block measured 0.58 PF/s, see profiles/).  The DMA destination is lane-linear, the
-//    per-lane SOURCE address is free -- that is where the implicit-GEMM gather lives: 3x3 halo / zero
-//    padding (lanes point at a 16-byte zero word), stride 2, nearest-x2 upsample folding and the
-//    two-source skip concat are all just per-lane source pointers.
+//  * One workgroup = 8 waves (block tiles 192x320, 192x256, 256x256, 256x128, 256x64, 512x64, 128x128) or 4 / 2 waves (128x128, 128x64,
+//    64x64, 256x64), BK = 64.  Each wave owns a 96x80 / 96x64 sub-tile as 16x16x32 fragments or a 128x64 .. 32x32 one as 32x32x16
+//    fragments.  The MFMA is issued "swapped" -- D = Wfrag * Xfrag^T, rows = output channel n, cols = pixel/token m -- so that every
+//    lane ends up with 4 CONSECUTIVE output channels of one row in each accumulator quad.
+//  * A (activations, NHWC bf16) and W (packed [N][K], K contiguous) tiles go HBM/L2 -> LDS by LDS-DMA through buffer descriptors
+//    (buffer_load_dwordx4 ... offen lds, 16 B per lane, no VGPR round trip) into a ring of STAGES LDS buffers; ONE s_barrier per
+//    K-tile preceded by a COUNTED s_waitcnt vmcnt(N) so the younger tiles' DMAs stay in flight across it.  The DMA destination is
+//    lane-linear, the per-lane SOURCE offset is free -- that is where the implicit-GEMM gather lives: 3x3 halo / zero padding (an
+//    out-of-range offset returns zeros), stride 2, nearest-x2 upsample folding, the two-source skip concat and `zero_rows` are all
+//    just per-lane source offsets.  The K loop itself ("rotated": barrier in front of the last k-step's MFMAs) is described at the loop.
 //  * LDS tiles are unpadded [rows][64] bf16 with the 16-byte chunk index XOR-swizzled by (row>>1)&7,
-//    applied on the DMA source address and again on the fragment reads (cdna_hip_programming.md rule 21):
+//    applied on the DMA source offset and again on the fragment reads (cdna_hip_programming.md rule 21):
 //    the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte slots of the 256-byte bank row.
+//  * Epilogue: accumulators -> wave-private fp32 LDS tile -> 16-byte rows; bias / time-embedding row / residual / GEGLU in registers;
+//    buffer stores (no predicates); V^T of the fused q|k|v projection written transposed.  Split-K partials go to an fp32 workspace.
 //  * Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous run of M-tiles and
 //    walks all N-tiles of an A tile back to back (cdna_hip_programming.md T1, bijective form).
+//  * What bounds it: with real operands the MFMA + LDS loop without any global loads sustains 1.1-1.5 PF/s (power), and
+//    a CU fills its LDS from L2 at 23-37 B per cycle; the 192x320 tile (120 FLOP per staged byte) sits at both limits at once.
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 
@@ -55,7 +56,7 @@ struct GemmArgs {
     float* ws;
     int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
-    int debug;  // ablation (tools/bench_ops.py --ablate): bit0 = skip steady-state loads, bit1 = skip MFMAs, bit2 = per-workgroup
+    int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
                 // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)
 };
 }  // namespace pcdm_gemm_detail
