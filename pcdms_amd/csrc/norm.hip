@@ -5,9 +5,13 @@
 // keeps per-channel accumulators / affine coefficients in registers; a row of C channels is read by
 // C/8 consecutive lanes (fully coalesced).  Reductions: registers -> LDS across row-lanes ->
 // per-channel sums in LDS -> fp32 per-(chunk, group) partials; the apply kernel's prologue finishes them in
-// fp64 (fixed order, deterministic), so a GroupNorm is two launches.  The GroupNorm input may be the virtual concat of two tensors so the
-// up-block skip concat (ref stage2_inpaint_unet_2d_condition.py:792-793) is never materialised
-// on the input side.
+// fp64 (fixed order, deterministic).  Three GroupNorm paths, chosen per shape by pcdm_groupnorm:
+//   gn_fused_kernel    one workgroup holds the whole (image, group set) slab in registers: one launch, one pass (small feature maps)
+//   gn_cluster_kernel  the slab split over S = 2 / 4 / 8 co-resident workgroups that exchange partial sums inside the launch
+//                      (<= 256 workgroups = one per CU; counters in their own region of the workspace): one launch, one pass
+//   gn_stats + gn_apply  two launches (level 0's widest tensors, the VAE)
+// The GroupNorm input may be the virtual concat of two tensors so the up-block skip concat
+// (ref stage2_inpaint_unet_2d_condition.py:792-793) is never materialised on the input side.
 #include "pcdm_device.h"
 #include "../../include/pcdm.h"
 #include <cstdlib>
