@@ -68,3 +68,10 @@ def image_proj_p(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
     h = F.gelu(F.linear(x, sd["net.0.weight"], sd["net.0.bias"]))
     h = F.layer_norm(h, (h.shape[-1],), sd["net.3.weight"], sd["net.3.bias"], 1e-5)
     return F.linear(h, sd["net.4.weight"], sd["net.4.bias"])
+
+
+def image_projection(sd: Dict[str, Tensor], id_embeds: Tensor, num_tokens: int) -> Tensor:
+    """``ImageProjection`` (ref src/pipelines/PCDMs_pipeline.py:154-173): [B,E] -> [B,num_tokens,D]."""
+    x = F.linear(F.gelu(F.linear(id_embeds, sd["proj.0.weight"], sd["proj.0.bias"])), sd["proj.2.weight"], sd["proj.2.bias"])
+    D = sd["norm.weight"].shape[0]
+    return F.layer_norm(x.reshape(-1, num_tokens, D), (D,), sd["norm.weight"], sd["norm.bias"], 1e-5)

@@ -177,3 +177,46 @@ class ImageProjModel_p(_HipModule):
         return y.view(B, L, self.out_dim).to(x.dtype if x.dtype.is_floating_point else torch.float32)
 
     forward = __call__
+
+
+class ImageProjection(_HipModule):
+    """``ImageProjection`` of the notebook pipeline (ref src/pipelines/PCDMs_pipeline.py:154-173): Linear(E -> 2E) -> GELU ->
+    Linear(2E -> num_tokens * D) -> reshape [-1, num_tokens, D] -> LayerNorm(D).  The same three kernels as ``ImageProjModel_p``."""
+    _name = "ImageProjection"
+
+    def __init__(self, cross_attention_dim: int = 768, clip_embeddings_dim: int = 512, num_tokens: int = 4):
+        super().__init__()
+        if clip_embeddings_dim % 64 or cross_attention_dim % 8:
+            raise NotImplementedError("clip_embeddings_dim must be a multiple of 64, cross_attention_dim of 8")
+        self.cross_attention_dim, self.clip_embeddings_dim, self.num_tokens = cross_attention_dim, clip_embeddings_dim, num_tokens
+
+    def expected_shapes(self):
+        E, D, T = self.clip_embeddings_dim, self.cross_attention_dim, self.num_tokens
+        return {"proj.0.weight": (2 * E, E), "proj.0.bias": (2 * E,), "proj.2.weight": (D * T, 2 * E), "proj.2.bias": (D * T,),
+                "norm.weight": (D,), "norm.bias": (D,)}
+
+    def _pack(self):
+        self._ready()
+        sd, dev = self._sd, self._device
+        self._w = dict(fc1=ops.pack_linear(sd["proj.0.weight"], sd["proj.0.bias"], dev),
+                       fc2=ops.pack_linear(sd["proj.2.weight"], sd["proj.2.bias"], dev),
+                       ln=(sd["norm.weight"].to(dev).contiguous(), sd["norm.bias"].to(dev).contiguous()))
+
+    @torch.no_grad()
+    def __call__(self, id_embeds: torch.Tensor) -> torch.Tensor:
+        """id_embeds [B, E] -> [B, num_tokens, D] (bf16 compute, returned in the input's dtype)."""
+        if self._w is None:
+            self._pack()
+        w = self._w
+        E, D, T = self.clip_embeddings_dim, self.cross_attention_dim, self.num_tokens
+        x = id_embeds.reshape(-1, id_embeds.shape[-1])
+        if x.shape[1] != E:
+            raise ValueError(f"expected last dim {E}, got {x.shape[1]}")
+        M = x.shape[0]
+        xb = ops.f32_to_bf16(x.to(self._device, torch.float32).contiguous(), self._buf("x", (M, E)))
+        h = ops.gemm(xb, w["fc1"], self._buf("h", (M, 2 * E)), act=ops.ACT_GELU)
+        y = ops.gemm(h, w["fc2"], self._buf("y", (M, D * T)))
+        n = ops.layernorm(y.view(M * T, D), w["ln"][0], w["ln"][1], 1e-5, torch.empty(M * T, D, dtype=BF16, device=self._device))
+        return n.view(M, T, D).to(id_embeds.dtype if id_embeds.dtype.is_floating_point else torch.float32)
+
+    forward = __call__

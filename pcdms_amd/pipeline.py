@@ -43,6 +43,24 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
     return ops.rescale_noise_cfg(a, b, torch.empty_like(a), guidance_rescale).to(noise_cfg.dtype)
 
 
+def retrieve_timesteps(scheduler, num_inference_steps: Optional[int] = None, device=None, timesteps: Optional[List[int]] = None,
+                       **kwargs):
+    """``retrieve_timesteps`` of the notebook pipeline (ref src/pipelines/PCDMs_pipeline.py:190-231): calls
+    ``scheduler.set_timesteps`` and returns ``(scheduler.timesteps, num_inference_steps)``; a custom ``timesteps`` list is passed
+    on only to schedulers whose ``set_timesteps`` has a ``timesteps`` parameter, anything else is a ``ValueError`` (same message)."""
+    if timesteps is not None:
+        if "timesteps" not in set(inspect.signature(scheduler.set_timesteps).parameters.keys()):
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
+                             f" timestep schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
+        timesteps = scheduler.timesteps
+        num_inference_steps = len(timesteps)
+    else:
+        scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+        timesteps = scheduler.timesteps
+    return timesteps, num_inference_steps
+
+
 class Stage2_InpaintDiffusionPipeline:
     #: False in ``Simple_Stage2_InpaintDiffusionPipeline`` (ref :544-887): no stage-1 embedding, i.e. no class_labels and
     #: only the 257 projected source-image tokens as context
@@ -406,8 +424,9 @@ class PCDMsPipeline(Simple_Stage2_InpaintDiffusionPipeline):
     ``cond_pose`` (the pose feature, un-doubled: it broadcasts over the batch, :1127), ``prompt_embeds`` = the projected
     DINOv2 tokens and ``negative_prompt_embeds`` = ``image_proj_model(zeros)`` (cell 37) -- a NON-zero unconditional
     context; no ``class_labels``.  The input is ``cat([latents, mask, simg_mask_latents], 1)`` doubled for CFG (:1117-1119),
-    which is what ``pcdm_assemble_input`` builds.  Text prompts, IP-adapter images, LoRA scale, ``clip_skip``, custom
-    ``timesteps`` and the safety checker are SD boilerplate the notebook never uses: ``NotImplementedError`` when given."""
+    which is what ``pcdm_assemble_input`` builds.  Text prompts, IP-adapter images, LoRA scale, ``clip_skip`` and the safety
+    checker are SD boilerplate the notebook never uses: ``NotImplementedError`` when given.  ``timesteps`` goes through
+    ``retrieve_timesteps`` as in the reference (:1081): a ``ValueError`` unless the scheduler's ``set_timesteps`` accepts it."""
 
     @torch.no_grad()
     def __call__(self, simg_mask_latents=None, mask=None, cond_pose=None, prompt=None, height: Optional[int] = None,
@@ -418,8 +437,8 @@ class PCDMsPipeline(Simple_Stage2_InpaintDiffusionPipeline):
                  guidance_rescale: float = 0.0, clip_skip=None, callback_on_step_end=None,
                  callback_on_step_end_tensor_inputs=("latents",), mode: Optional[str] = None, use_graph: bool = True, **kwargs):
         if prompt is not None or negative_prompt is not None or ip_adapter_image is not None or cross_attention_kwargs is not None \
-                or clip_skip is not None or timesteps is not None:
-            raise NotImplementedError("text prompts / IP-adapter / LoRA / clip_skip / custom timesteps are not part of the PCDMs path")
+                or clip_skip is not None:
+            raise NotImplementedError("text prompts / IP-adapter / LoRA / clip_skip are not part of the PCDMs path")
         if prompt_embeds is None or simg_mask_latents is None or mask is None or cond_pose is None:
             raise ValueError("simg_mask_latents, mask, cond_pose and prompt_embeds are required")
         device = self.device
@@ -447,8 +466,7 @@ class PCDMsPipeline(Simple_Stage2_InpaintDiffusionPipeline):
         for name, t in (("mask", mask_t), ("simg_mask_latents", masked), ("cond_pose", pose_cond)):
             if t.shape[0] not in (1, rep * bs * N):
                 raise ValueError(f"{name}: batch {t.shape[0] // (rep if t.shape[0] != 1 else 1)} does not match {bs * N} samples")
-        self.scheduler.set_timesteps(num_inference_steps, device=device)
-        ts = self.scheduler.timesteps
+        ts, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps)   # ref :1081
         lat = self.prepare_latents(bs * N, 4, height, width, torch.float32, device, generator, latents).contiguous()
         extra = self.prepare_extra_step_kwargs(generator, eta)
         cb = None

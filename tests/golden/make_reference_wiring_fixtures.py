@@ -77,15 +77,20 @@ def main():
                    return_dict=False)[0]
         eps_obj = unet(sample, 621, encoder_hidden_states=ehs, class_labels=cl, my_pose_cond=pose).sample
     assert torch.equal(eps, eps_obj)
-    np.savez_compressed(HERE / "ref_wiring_unet.npz", sample=sample.numpy(), timestep=621, ehs=ehs.numpy(),
-                        class_labels=cl.numpy(), pose=pose.numpy(), eps=eps.float().numpy(), **meta)
+    if not (HERE / "ref_wiring_unet.npz").exists() or "--force" in sys.argv:
+        np.savez_compressed(HERE / "ref_wiring_unet.npz", sample=sample.numpy(), timestep=621, ehs=ehs.numpy(),
+                            class_labels=cl.numpy(), pose=pose.numpy(), eps=eps.float().numpy(), **meta)
 
     # ---- fixture 2/3: the reference pipeline __call__ (DDIM 4 steps / UniPC 4 steps), one pair, N=2, guidance 2.0
     from src.pipelines.stage2_inpaint_pipeline import Stage2_InpaintDiffusionPipeline as RefPipe
     from tests.golden import diffusers_stub
     N, h, w, L = 2, 8, 16, 5
     inp = synth_inputs(cfg, h, w, N, L_img=L)
-    for kind, steps in (("ddim", 4), ("unipc", 4)):
+    # (kind, steps, guidance_rescale, file suffix); the third run exercises ``rescale_noise_cfg`` inside the reference's own loop
+    # (ref :510-516; the shipped driver passes 0.0).  Existing files are kept unless --force (np.savez output is not byte-stable).
+    for kind, steps, gr, suffix in (("ddim", 4, 0.0, "ddim"), ("unipc", 4, 0.0, "unipc"), ("ddim", 4, 0.7, "ddim_gr07")):
+        if (HERE / f"ref_wiring_pipeline_{suffix}.npz").exists() and "--force" not in sys.argv:
+            continue
         vae = diffusers_stub.FakeVAE(inp["masked_latents"] / 0.18215)
         pipe = RefPipe(vae=vae, unet=unet, scheduler=diffusers_stub.make_scheduler(kind))
         trace = []
@@ -94,12 +99,12 @@ def main():
                        s_img_proj_f=inp["s_img_proj_f"], st_pose_f=inp["st_pose_f"],
                        pred_t_img_embed=inp["pred_t_img_embed"], num_images_per_prompt=N, guidance_scale=2.0,
                        generator=None, num_inference_steps=steps, latents=inp["latents"].clone(),
-                       guidance_rescale=0.0, output_type="pt",
+                       guidance_rescale=gr, output_type="pt",
                        callback=lambda i, t, lat: trace.append(lat.float().clone()), callback_steps=1)
         final = trace[-1]
         # decode() is the identity in the stub, so .images == final latents / scaling_factor
         assert torch.allclose(out.images.float() * 0.18215, final, atol=1e-6)
-        np.savez_compressed(HERE / f"ref_wiring_pipeline_{kind}.npz", steps=steps, N=N,
+        np.savez_compressed(HERE / f"ref_wiring_pipeline_{suffix}.npz", steps=steps, N=N, guidance_rescale=gr,
                             final_latents=final.numpy(), trace=torch.stack(trace).numpy(),
                             **{k: v.numpy() for k, v in inp.items()}, **meta)
         print(kind, "final latents std", float(final.std()))

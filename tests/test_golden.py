@@ -49,15 +49,16 @@ def test_oracle_reproduces_reference_forward():
     assert torch.allclose(eps, _t(z, "eps"), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("kind", ["ddim", "unipc"])
+@pytest.mark.parametrize("kind", ["ddim", "unipc", "ddim_gr07"])
 def test_oracle_reproduces_reference_pipeline(kind):
+    """``ddim_gr07``: the reference's loop with guidance_rescale=0.7, i.e. its own rescale_noise_cfg (ref :510-516) inside the loop."""
     z, cfg, sd = _load(f"ref_wiring_pipeline_{kind}.npz")
-    sch = DDIMOracle() if kind == "ddim" else UniPCOracle()
+    sch = UniPCOracle() if kind == "unipc" else DDIMOracle()
     trace = []
     out = stage2_sample(sd, cfg, sch, masked_latents=_t(z, "masked_latents"), s_img_proj_f=_t(z, "s_img_proj_f"),
                         st_pose_f=_t(z, "st_pose_f"), pred_t_img_embed=_t(z, "pred_t_img_embed"),
                         latents=_t(z, "latents"), num_images_per_prompt=int(z["N"]), guidance_scale=2.0,
-                        num_inference_steps=int(z["steps"]))
+                        num_inference_steps=int(z["steps"]), guidance_rescale=float(z["guidance_rescale"]) if "guidance_rescale" in z else 0.0)
     assert _rel(out, _t(z, "final_latents")) < 1e-2, _rel(out, _t(z, "final_latents"))
 
 
@@ -80,7 +81,7 @@ def test_hip_reproduces_reference_forward(gpu_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["ddim", "unipc"])
+@pytest.mark.parametrize("kind", ["ddim", "unipc", "ddim_gr07"])
 def test_hip_reproduces_reference_pipeline(gpu_backend, kind):
     from pcdms_amd.pipeline import Stage2_InpaintDiffusionPipeline
     from pcdms_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
@@ -88,12 +89,12 @@ def test_hip_reproduces_reference_pipeline(gpu_backend, kind):
     z, cfg, sd = _load(f"ref_wiring_pipeline_{kind}.npz")
     dev = gpu_backend.device
     m = _product_unet(cfg, sd, dev)
-    sch = (DDIMScheduler if kind == "ddim" else UniPCMultistepScheduler).from_config(SD21)
+    sch = (UniPCMultistepScheduler if kind == "unipc" else DDIMScheduler).from_config(SD21)
     pipe = Stage2_InpaintDiffusionPipeline(m, sch)
     h, w = z["latents"].shape[-2:]
     out = pipe(height=h * 8, width=w * 8, masked_latents=_t(z, "masked_latents").to(dev),
                s_img_proj_f=_t(z, "s_img_proj_f").to(dev), st_pose_f=_t(z, "st_pose_f").to(dev),
                pred_t_img_embed=_t(z, "pred_t_img_embed").to(dev), latents=_t(z, "latents").to(dev),
                num_images_per_prompt=int(z["N"]), guidance_scale=2.0, num_inference_steps=int(z["steps"]),
-               output_type="latent").latents
+               guidance_rescale=float(z["guidance_rescale"]) if "guidance_rescale" in z else 0.0, output_type="latent").latents
     assert _rel(out, _t(z, "final_latents")) < 5e-2, _rel(out, _t(z, "final_latents"))
