@@ -147,6 +147,13 @@ int pcdm_f32_to_bf16(const float* x, void* y, int64_t n, pcdm_stream_t s);
  * Optionally writes the guided eps (eps_out) and x0 = c0x*x + c0e*eps is left to the host scheduler. */
 int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x, const float* noise, float* x_prev,
                   float* eps_out, const float* coef, const int32_t* step_dev, int64_t n, pcdm_stream_t s);
+/* CFG combine + diffusers UniPCMultistepScheduler.step (the shipped driver's scheduler: stage2_batchtest_inpaint_model.py:132;
+ * SURVEY.md Appendix A-10; solver order <= 2) as one kernel on static state, replayable from a hipGraph.  Row *step_dev of the DEVICE
+ * table coef[step][12] = {a_x, a_e, use_corrector, c_last, c_m1, c_m2, c_mt, p_x, p_mt, p_m1, 0, 0}:
+ *   m_t = a_x x + a_e eps_guided;  x_c = use_corrector ? c_last last + c_m1 m1 + c_m2 m2 + c_mt m_t : x;  x' = p_x x_c + p_mt m_t + p_m1 m1
+ * then, in place: x <- x', m2 <- m1, m1 <- m_t, last <- x_c (all fp32 [n]; zero m1 / m2 / last before step 0). */
+int pcdm_unipc_step(const float* eps, int cfg, float g, float* x, float* m1, float* m2, float* last, const float* coef,
+                    const int32_t* step_dev, int64_t n, pcdm_stream_t s);
 /* Stage-1 prior: CFG combine (src/pipelines/stage1_prior_pipeline.py:467-471) + diffusers
  * UnCLIPScheduler.step (:478-483) + optional affine read-out (post_process_latents, stage1_prior_transformer.py:299-301).
  * pred [2N or N, n/N] fp32 (uncond rows first); HOST coefficients c8 = {p_x, p_e, clip, c_x0, c_x, c_noise, out_scale,

@@ -62,6 +62,7 @@ _SIGS = {
     "pcdm_nhwc_bf16_to_nchw_f32": ([_P, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_f32_to_bf16": ([_P, _P, _L, _P], C.c_int),
     "pcdm_cfg_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
+    "pcdm_unipc_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
     "pcdm_unclip_step": ([_P, _I, _F, _P, _P, _P, C.POINTER(_F), _L, _P], C.c_int),
     "pcdm_lincomb": ([_P, _I, C.POINTER(_P), C.POINTER(_F), _L, _P], C.c_int),
     "pcdm_rescale_noise_cfg": ([_P, _P, _P, _I, _L, _F, _P], C.c_int),

@@ -142,6 +142,31 @@ __global__ void cfg_step_kernel(const float* __restrict__ eps, int cfg, float g,
     }
 }
 
+// UniPCMultistepScheduler.step (order <= 2, predict_x0, bh1 / bh2) as ONE elementwise kernel on static
+// state slots, so the whole UniPC update is graph-replayable: the step's twelve host-computed scalars come from a DEVICE table
+// row selected by the device step counter.
+//   m_t   = c[0] x + c[1] eps                                   (x0-prediction, convert_model_output)
+//   x_c   = c[2] != 0 ? c[3] last + c[4] m1 + c[5] m2 + c[6] m_t : x     (corrector; m1 = newest stored output, m2 the one before)
+//   x'    = c[7] x_c + c[8] m_t + c[9] m1                        (predictor, after the history shift m_t -> m1 -> m2)
+// and the state advances in place: x <- x', m2 <- m1, m1 <- m_t, last <- x_c.  Every element is owned by one thread.
+__global__ void unipc_step_kernel(const float* __restrict__ eps, int cfg, float g, float* __restrict__ x, float* __restrict__ m1,
+                                  float* __restrict__ m2, float* __restrict__ last, const float* __restrict__ coef,
+                                  const int32_t* __restrict__ step_dev, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* c = coef + 12 * (step_dev ? *step_dev : 0);
+    float e = eps[i];
+    if (cfg) e = e + g * (eps[n + i] - e);
+    const float xi = x[i], a1 = m1[i], a2 = m2[i];
+    const float mt = c[0] * xi + c[1] * e;
+    float xc = xi;
+    if (c[2] != 0.f) xc = c[3] * last[i] + c[4] * a1 + c[5] * a2 + c[6] * mt;
+    x[i] = c[7] * xc + c[8] * mt + c[9] * a1;
+    m2[i] = a1;
+    m1[i] = mt;
+    last[i] = xc;
+}
+
 // UnCLIPScheduler.step on a [N, n/N] vector (stage-1 prior): guided prediction -> x0 -> clip -> posterior mean (+ noise),
 // then an optional affine read-out (post_process_latents).  c = {p_x, p_e, clip, c_x0, c_x, c_noise, out_scale, out_shift}.
 struct UnclipArgs { float c[8]; };
@@ -349,6 +374,14 @@ extern "C" int pcdm_cfg_step(const float* eps, int cfg, float g, const float* x,
     if (!eps || n <= 0 || (x_prev && (!x || !coef))) return -1;
     PCDM_LAUNCH(cfg_step_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, eps, cfg, g, x, noise, x_prev, eps_out,
                 coef, step_dev, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_unipc_step(const float* eps, int cfg, float g, float* x, float* m1, float* m2, float* last, const float* coef,
+                               const int32_t* step_dev, int64_t n, pcdm_stream_t s) {
+    if (!eps || !x || !m1 || !m2 || !last || !coef || n <= 0) return -1;
+    PCDM_LAUNCH(unipc_step_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, eps, cfg, g, x, m1, m2, last, coef, step_dev, n);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

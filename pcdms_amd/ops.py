@@ -480,6 +480,17 @@ def cfg_step(eps: torch.Tensor, cfg: bool, g: float, x: Optional[torch.Tensor], 
                                   _ptr(coef), _ptr(step_dev), n, _stream(eps)), "pcdm_cfg_step")
 
 
+def unipc_step(eps: torch.Tensor, cfg: bool, g: float, x: torch.Tensor, m1: torch.Tensor, m2: torch.Tensor, last: torch.Tensor,
+               coef: torch.Tensor, step_dev: Optional[torch.Tensor] = None) -> None:
+    """pcdm_unipc_step: CFG combine + one UniPC step in place on (x, m1, m2, last); coef fp32 [steps, 12] on the device."""
+    n = x.numel()
+    for t in (eps, x, m1, m2, last, coef):
+        _c(t, torch.float32)
+    assert eps.numel() == (2 * n if cfg else n) and m1.numel() == m2.numel() == last.numel() == n and coef.shape[-1] == 12
+    _chk(_lib.lib().pcdm_unipc_step(_ptr(eps), int(cfg), float(g), _ptr(x), _ptr(m1), _ptr(m2), _ptr(last), _ptr(coef),
+                                    _ptr(step_dev), n, _stream(x)), "pcdm_unipc_step")
+
+
 def unclip_step(pred: torch.Tensor, cfg: bool, g: float, x: torch.Tensor, noise: Optional[torch.Tensor], out: torch.Tensor,
                 coefs: Sequence[float]) -> torch.Tensor:
     """pcdm_unclip_step: coefs = (p_x, p_e, clip, c_x0, c_x, c_noise, out_scale, out_shift); fp32 tensors."""

@@ -7,11 +7,11 @@ kernels:
 
 * ``mode="reference"`` -- literally the reference's loop: ``cat`` inputs, ``self.unet(...)``,
   CFG combine, ``self.scheduler.step(...)`` with any scheduler object (UniPC / DDIM / DDPM).
-* ``mode="fused"`` (default when the scheduler is DDIM/DDPM-like, i.e. one linear update per step)
-  -- per step: ``pcdm_assemble_input`` -> UNet schedule -> ``pcdm_cfg_step`` (CFG + scheduler update
-  with device-side coefficient table) -> ``pcdm_advance_step``; the step is captured once in a
-  hipGraph and replayed ``num_inference_steps`` times (the step index lives in device memory), which
-  removes ~700 host launches per step from the critical path.
+* ``mode="fused"`` (default for DDIM with eta = 0 and for UniPC, the shipped driver's scheduler: both are per-step LINEAR
+  updates with host-known coefficients) -- per step: ``pcdm_assemble_input`` -> UNet schedule -> ``pcdm_cfg_step`` /
+  ``pcdm_unipc_step`` (CFG + scheduler update from a device-side coefficient table; UniPC's history lives in static slots)
+  -> ``pcdm_advance_step``; the step is captured once in a hipGraph and replayed ``num_inference_steps`` times (the step
+  index lives in device memory), which removes ~700 host launches per step from the critical path.
 
 VAE encode/decode are outside the hot path: pass ``masked_latents``
 (= vae.encode(vae_image).sample * scaling_factor, ref :443-444) and read ``output.latents``.
@@ -25,7 +25,7 @@ from typing import Any, Callable, List, Optional, Union
 import torch
 
 from . import ops
-from .schedulers import DDIMScheduler, DDPMScheduler
+from .schedulers import DDIMScheduler, DDPMScheduler, UniPCMultistepScheduler
 from .unet import Stage2_InapintUNet2DConditionModel
 
 
@@ -216,9 +216,11 @@ class Stage2_InpaintDiffusionPipeline:
         ``zero_uncond``: the unconditional half of ``feature_f`` is literal zeros (the UNet then skips that half of every cross-attention)."""
         linear = isinstance(self.scheduler, (DDIMScheduler, DDPMScheduler)) and eta == 0.0 \
             and not isinstance(self.scheduler, DDPMScheduler)
+        # UniPC (ref stage2_batchtest_inpaint_model.py:132): multistep, but still one linear map per step on static state slots
+        linear = linear or (isinstance(self.scheduler, UniPCMultistepScheduler) and self.scheduler.config.solver_order <= 2)
         mode = mode or ("fused" if linear else "reference")
         if mode == "fused" and not linear:
-            raise ValueError("mode='fused' needs a scheduler with one deterministic linear update per step (DDIM, eta=0)")
+            raise ValueError("mode='fused' needs a scheduler with one deterministic linear update per step (DDIM with eta=0, UniPC)")
 
         if mode == "reference":
             # the literal loop: bare unet(...) calls.  The UNet recognises the step-invariant tensors by identity (it keeps
@@ -271,14 +273,23 @@ class Stage2_InpaintDiffusionPipeline:
         B, h, w = st["B"], st["h"], st["w"]
         x_in = ops.assemble_input(st["lat"], st["rep"], st["mask"], st["masked"], st["x_in"])
         eps = unet._forward_nhwc(x_in, B, h, w, st["timesteps"], st["cond"], step_dev=st["step"])
+        cfg, g, e = st["rep"] == 2, st["g"], eps
         if st["gr"] > 0.0:   # CFG -> rescale_noise_cfg (ref :510-516) -> scheduler update
             n = eps.shape[0] // 2
             ops.cfg_step(eps, True, st["g"], None, None, None, eps_out=st["eps_g"])
             ops.rescale_noise_cfg(st["eps_g"], eps[n:], st["eps_g"], st["gr"])
-            ops.cfg_step(st["eps_g"], False, 1.0, st["lat"], st["lat"], st["coef"], st["step"])
+            cfg, g, e = False, 1.0, st["eps_g"]
+        if st["unipc"]:
+            ops.unipc_step(e, cfg, g, st["lat"], st["m1"], st["m2"], st["last"], st["coef"], st["step"])
         else:
-            ops.cfg_step(eps, st["rep"] == 2, st["g"], st["lat"], st["lat"], st["coef"], st["step"])
+            ops.cfg_step(e, cfg, g, st["lat"], st["lat"], st["coef"], st["step"])
         ops.advance_step(st["step"])
+
+    @staticmethod
+    def _zero_history(st):
+        if st.get("unipc"):
+            for k in ("m1", "m2", "last"):
+                st[k].zero_()
 
     def _run_fused(self, lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, g, eta, use_graph,
                    callback, callback_steps, guidance_rescale=0.0, zero_uncond=False):
@@ -290,17 +301,20 @@ class Stage2_InpaintDiffusionPipeline:
         rep = 2 if do_cfg else 1
         B = rep * N
         n0 = N if (do_cfg and zero_uncond) else 0
+        unipc = isinstance(self.scheduler, UniPCMultistepScheduler)
         key = (B, h, w, n, rep, n0, tuple(feature_f.shape), tuple(mask.shape), tuple(masked.shape), tuple(pose_cond.shape),
-               prior_embed is None)
+               prior_embed is None, unipc)
         st = self._st if self._graph_key == key else {}
         if not st:
-            st.update(B=B, h=h, w=w, rep=rep,
+            st.update(B=B, h=h, w=w, rep=rep, unipc=unipc,
                       lat=torch.empty_like(lat), mask=torch.empty_like(mask), masked=torch.empty_like(masked),
                       eps_g=torch.empty_like(lat),
                       x_in=torch.empty(B, h, w, 64, dtype=ops.BF16, device=dev),
                       step=torch.zeros(1, dtype=torch.int32, device=dev),
                       timesteps=torch.empty(n, dtype=torch.int64, device=dev),
-                      coef=torch.empty(n, 4, dtype=torch.float32, device=dev))
+                      coef=torch.empty(n, 12 if unipc else 4, dtype=torch.float32, device=dev))
+            if unipc:   # UniPC history (two stored x0-predictions, last corrected sample): static slots, zeroed per call
+                st.update(m1=torch.zeros_like(lat), m2=torch.zeros_like(lat), last=torch.zeros_like(lat))
             self._graph = None
         # Per call: the static input slots the captured step reads are refilled, and the step-invariant conditioning (class
         # embedding, NHWC pose, the 16 cross-attention K / V^T) is recomputed EAGERLY into the UNet's shape-keyed buffers --
@@ -312,7 +326,7 @@ class Stage2_InpaintDiffusionPipeline:
         st["masked"].copy_(masked)
         st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
         st["timesteps"].copy_(timesteps.to(dev))
-        st["coef"].copy_(self.scheduler.coefficient_table(eta, device=dev))
+        st["coef"].copy_(self.scheduler.coefficient_table(device=dev) if unipc else self.scheduler.coefficient_table(eta, device=dev))
         st["g"] = g
         if st.get("gr", guidance_rescale) != guidance_rescale:
             self._graph = None
@@ -322,6 +336,7 @@ class Stage2_InpaintDiffusionPipeline:
         if st.get("w_gen") != w_gen:
             self._graph = None
         st["step"].zero_()
+        self._zero_history(st)
         self._st, self._graph_key = st, key
         if use_graph and dev.type == "cuda":
             if self._graph is None or self._st.get("g_captured") != g:
@@ -331,12 +346,14 @@ class Stage2_InpaintDiffusionPipeline:
                 torch.cuda.synchronize()
                 st["lat"].copy_(lat0)
                 st["step"].zero_()
+                self._zero_history(st)
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime while we capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._step_eager(st)
                 st["lat"].copy_(lat0)
                 st["step"].zero_()
+                self._zero_history(st)
                 self._graph = graph
                 st["g_captured"] = g
                 w_gen = (id(unet), getattr(unet, "_pack_gen", 0), ops.workspace_generation(dev))   # (the warm-up may have grown it)

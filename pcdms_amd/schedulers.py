@@ -326,6 +326,31 @@ class UniPCMultistepScheduler(_Base):
         cm[0] -= ct
         return float(sigma_t / sigma_s), cm, ct
 
+    def coefficient_table(self, device=None) -> torch.Tensor:
+        """fp32 [n, 12] rows for ``pcdm_unipc_step`` (include/pcdm.h): the scalars ``step`` would compute at step i of a fresh run --
+        the order bookkeeping (``lower_order_nums``, ``this_order``, ``lower_order_final``) depends on i and n only, so the whole
+        multistep update is a per-step linear map on (x, eps, m1, m2, last_sample) with host-known coefficients."""
+        c, n = self.config, len(self._ts_list)
+        if c.solver_order > 2:
+            raise NotImplementedError("fused UniPC: solver_order <= 2")
+        rows = np.zeros((n, 12), dtype=np.float64)
+        lower, this_order = 0, 1
+        for i in range(n):
+            _, alpha_t, sigma_t = self._als(i)
+            rows[i, 0], rows[i, 1] = 1.0 / float(alpha_t), -float(sigma_t) / float(alpha_t)
+            if i > 0 and (i - 1) not in c.disable_corrector:
+                cl, cm, ct = self.corrector_coefficients(i, this_order)
+                rows[i, 2], rows[i, 3], rows[i, 6] = 1.0, cl, ct
+                rows[i, 4:4 + len(cm)] = cm
+            order = min(c.solver_order, n - i) if c.lower_order_final else c.solver_order
+            this_order = min(order, lower + 1)
+            cx, cm = self.predictor_coefficients(i, this_order)
+            rows[i, 7] = cx
+            rows[i, 8:8 + len(cm)] = cm
+            if lower < c.solver_order:
+                lower += 1
+        return torch.from_numpy(rows.astype(np.float32)).to(device)
+
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = True):
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")

@@ -8,10 +8,16 @@ What is compared (reference: /root/reference/src/pipelines/stage2_inpaint_pipeli
 * ONE forward at the oracle's own state -- eps at steps 0 / 10 / 25 / 49 with the fixture's latents as input (M = 45 056
   rows through every GEMM / conv tile the bench uses): rel-L2 <= FWD_TOL;
 * the 50-step hipGraph trajectory from the same initial latents -- latents before steps 10 / 25 / 49 and the final latents:
-  rel-L2 <= TRAJ_TOL (bf16 activations between kernels vs the fp32 oracle, error carried through 50 steps);
+  rel-L2 <= TRAJ_TOL (bf16 activations between kernels vs the fp32 oracle, error carried through 50 steps).  The latents are
+  ~85 % a deterministic fp32 rescale of the initial noise (cosine(lat_final, lat_0) = 0.988 in the fixture), so the check that
+  bites is the EPS-DRIVEN PART ``lat_i - c_x(i) * lat_0`` (c_x(i) = the product of the DDIM x-coefficients up to step i, obtained
+  by running the oracle scheduler with eps = 0): everything the UNet contributed, rel-L2 <= EPS_PART_TOL;
 * uint8 canvases after VAE decode (HIP VAE on the HIP latents vs oracle VAE on the oracle latents): mean |diff| <= PIX_TOL
   levels of 255, and per-canvas mean within PIX_MEAN_TOL levels;
-* configs[2]'s per-GPU share: one forward at N = 8 (UNet batch 16).
+* configs[2]'s per-GPU share (N = 8, UNet batch 16): forwards at TWO oracle states (step 0: ``b16_eps``; step 25:
+  ``fullsize_b16_mid.npz``) and a 50-step N = 8 hipGraph run whose first four samples reproduce the oracle's N = 4 trajectory
+  (samples are independent: same pair, per-sample noise) and whose two halves are mutually consistent;
+* configs[4]'s per-GPU share (fp8 attention, N = 16, UNet batch 32): fp8 forward vs the bf16 path, and run-to-run determinism.
 
 Tolerances are stated here and were set from the measured values on MI355X (recorded in DESIGN.md §5)."""
 from __future__ import annotations
@@ -34,8 +40,10 @@ from tests.test_unet import _kwargs
 FIXTURE = Path(__file__).resolve().parent / "golden" / "fullsize_config2.npz"
 FWD_TOL = 2.5e-2      # one forward, rel-L2 of the guided eps: the suite's forward tolerance (tests/test_unet.py); measured 0.95e-2 .. 1.67e-2
 FP8_FWD_TOL = 6e-2    # one forward with fp8 (e4m3) attention operands -- configs[4]'s own, looser tolerance
-TRAJ_TOL = 5e-3       # latents along / at the end of the 50-step trajectory (measured 0.7e-3 .. 0.8e-3: the DDIM update is dominated by
+TRAJ_TOL = 1.5e-3     # latents along / at the end of the 50-step trajectory (measured 0.7e-3 .. 0.8e-3: the DDIM update is dominated by
                       # its deterministic rescale of the latents, which both sides compute in fp32)
+EPS_PART_TOL = 2.5e-2  # the eps-driven part of the same latents, lat_i - c_x(i) lat_0: the accumulated UNet contribution (one forward: FWD_TOL)
+FP8_VS_BF16_TOL = 2e-2  # guided eps with fp8 attention vs the bf16-attention path, same weights and inputs (UNet batch 32)
 PIX_TOL = 1.0         # mean absolute difference in uint8 levels over a canvas (measured 0.34; bf16 VAE alone 0.34)
 PIX_MEAN_TOL = 0.25   # |mean(canvas) - mean(oracle canvas)| in uint8 levels (measured <= 0.022)
 
@@ -73,6 +81,17 @@ def _guided_eps(m, cfg, inp, lat, t, N, dev):
     return u + 2.0 * (cn - u)
 
 
+def _ddim_x_coefficients(steps: int):
+    """c_x(i): latents before step i = c_x(i) * lat_0 + (eps-driven part); from the ORACLE scheduler run with eps = 0."""
+    sch = DDIMOracle()
+    sch.set_timesteps(steps)
+    x, cx = torch.ones(1, dtype=torch.float64), {0: 1.0}
+    for i, t in enumerate(sch.timesteps):
+        x = sch.step(torch.zeros_like(x), t, x)
+        cx[i + 1] = float(x)
+    return cx
+
+
 @pytest.mark.gpu
 def test_single_forward_at_oracle_states(full):
     fx, cfg, m, dev = full
@@ -106,6 +125,19 @@ def test_50_step_trajectory_and_pixels(full):
     rels["final"] = _rel(out, fx["lat_final"])
     print("full-size 50-step trajectory rel-L2 (latents before step i / final):", {k: round(v, 5) for k, v in rels.items()})
     assert max(rels.values()) <= TRAJ_TOL, rels
+    # the eps-driven part: subtract the deterministic image of the initial noise, c_x(i) * lat_0
+    cx = _ddim_x_coefficients(steps)
+    lat0 = torch.from_numpy(fx["lat_0"])
+    parts = {}
+    for i in [int(v) for v in fx["check"]] + [steps]:
+        if i == 0:
+            continue
+        hip = (seen[i] if i < steps else out).float().cpu() - cx[i] * lat0
+        ref = torch.from_numpy(fx[f"lat_{i}"] if i < steps else fx["lat_final"]) - cx[i] * lat0
+        parts[i] = ((hip - ref).norm() / ref.norm()).item()
+        assert ref.norm() > 0.02 * lat0.norm()
+    print("full-size 50-step trajectory, eps-driven part rel-L2 (before step i / after the last):", {k: round(v, 5) for k, v in parts.items()})
+    assert max(parts.values()) <= EPS_PART_TOL, parts
     # a second call with the graph already captured reproduces the first bit for bit
     out2 = pipe(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
                 st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
@@ -161,3 +193,72 @@ def test_batch16_forward_configs2_share(full):
     r = _rel(eps, fx["b16_eps"])
     print("full-size UNet-batch-16 forward rel-L2:", round(r, 5))
     assert r <= FWD_TOL, r
+    # second oracle state: the middle of the schedule (tests/golden/make_fullsize_b16_fixture.py)
+    mid_path = FIXTURE.parent / "fullsize_b16_mid.npz"
+    if not mid_path.exists():
+        pytest.fail(f"{mid_path} missing: run tests/golden/make_fullsize_b16_fixture.py")
+    from tests.golden.make_fullsize_b16_fixture import mid_state_latents
+    mid = np.load(mid_path)
+    t = int(mid["t"])
+    assert t == int(sch.timesteps[int(mid["step"])])
+    lat = mid_state_latents(float(sch.alphas_cumprod[t]), N, h, w)
+    assert abs(float(lat.double().abs().sum()) - float(mid["lat_checksum"])) <= 1e-9 * float(mid["lat_checksum"])
+    r2 = _rel(_guided_eps(m, cfg, inp, lat, torch.tensor(t), N, dev), mid["eps"])
+    print("full-size UNet-batch-16 forward at step 25 rel-L2:", round(r2, 5))
+    assert r2 <= FWD_TOL, r2
+
+
+@pytest.mark.gpu
+def test_configs2_share_50_step_graph_run(full):
+    """BASELINE.json configs[2], one GPU's share: N = 8 samples of one pair (UNet batch 16), all 50 DDIM steps under the hipGraph.
+    Samples are independent given the pair, so with per-sample noise = [the N = 4 fixture's noise | fresh noise] the first four
+    must reproduce the ORACLE's N = 4 trajectory (fixture), and a second call must reproduce the first bit for bit."""
+    fx, cfg, m, dev = full
+    N, h, w = 8, 64, 88
+    steps = int(fx["steps"])
+    inp = synth_inputs(cfg, h, w, 4)
+    lat8 = torch.cat([inp["latents"], torch.randn(4, 4, h, w, generator=torch.Generator().manual_seed(77))])
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    kw = dict(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
+              st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), num_images_per_prompt=N,
+              guidance_scale=2.0, num_inference_steps=steps, output_type="latent")
+    out = pipe(latents=lat8.to(dev), **kw).latents
+    assert pipe._graph is not None and out.shape == (N, 4, h, w) and bool(torch.isfinite(out).all())
+    r = _rel(out[:4], fx["lat_final"])
+    cx = _ddim_x_coefficients(steps)[steps]
+    lat0 = inp["latents"]
+    ref = torch.from_numpy(fx["lat_final"]) - cx * lat0
+    rp = ((out[:4].float().cpu() - cx * lat0 - ref).norm() / ref.norm()).item()
+    print("configs[2] share, N = 8 50-step run: first four samples vs the oracle rel-L2", round(r, 5), "eps-driven part", round(rp, 5))
+    assert r <= TRAJ_TOL and rp <= EPS_PART_TOL, (r, rp)
+    # the other four samples carry the same pair: their statistics match the first four's (a property, not a pin)
+    s0, s1 = out[:4].float().std().item(), out[4:].float().std().item()
+    assert abs(s0 - s1) <= 0.05 * s0, (s0, s1)
+    out2 = pipe(latents=lat8.to(dev), **kw).latents
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.gpu
+def test_configs4_share_fp8_batch32(full):
+    """BASELINE.json configs[4], one GPU's share (batch 128 over 8 GPUs = N 16, UNet batch 32): the fp8-attention forward against the
+    bf16-attention forward of the same weights and inputs (no batch-32 oracle state is committed: 38 TFLOP of fp32 CPU work),
+    and bit-exact run-to-run determinism of the fp8 path."""
+    fx, cfg, m, dev = full
+    N, h, w = 16, 64, 88
+    inp = synth_inputs(cfg, h, w, N)
+    sch = DDIMOracle()
+    sch.set_timesteps(int(fx["steps"]))
+    t = sch.timesteps[25]
+    a = float(sch.alphas_cumprod[int(t)])
+    lat = a ** 0.5 * 0.9 * torch.randn(N, 4, h, w, generator=torch.Generator().manual_seed(31)) + (1 - a) ** 0.5 * inp["latents"]
+    ref = _guided_eps(m, cfg, inp, lat, t, N, dev)
+    m.set_attention_precision("fp8")
+    try:
+        e1 = _guided_eps(m, cfg, inp, lat, t, N, dev)
+        e2 = _guided_eps(m, cfg, inp, lat, t, N, dev)
+    finally:
+        m.set_attention_precision("bf16")
+    r = ((e1 - ref).norm() / ref.norm()).item()
+    print("configs[4] share, UNet batch 32: fp8-attention vs bf16-attention guided eps rel-L2", round(r, 5))
+    assert torch.equal(e1, e2) and bool(torch.isfinite(e1).all())
+    assert r <= FP8_VS_BF16_TOL, r

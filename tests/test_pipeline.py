@@ -81,11 +81,21 @@ def test_pipeline_unipc_and_identities(backend):
     ref = stage2_sample(sd, cfg, UniPCOracle(), num_images_per_prompt=N, guidance_scale=2.0,
                         num_inference_steps=steps, **inp)
     pipe = Stage2_InpaintDiffusionPipeline(m, UniPCMultistepScheduler.from_config(SD21))
-    out = _call(pipe, inp, backend.device, N, steps, h, w)
+    out = _call(pipe, inp, backend.device, N, steps, h, w, mode="reference")
     backend.sync()
     assert _rel(out, ref) <= 3e-2, _rel(out, ref)
-    with pytest.raises(ValueError):
-        _call(pipe, inp, backend.device, N, steps, h, w, mode="fused")
+    # the fused path (default for UniPC too): pcdm_unipc_step on static history slots + device coefficient table, hipGraph on the GPU
+    fused = _call(pipe, inp, backend.device, N, steps, h, w)
+    backend.sync()
+    assert _rel(fused, ref) <= 3e-2, _rel(fused, ref)
+    assert _same_path(fused, out), ((fused.float() - out.float()).norm() / out.float().norm()).item()
+    if not backend.is_emu:
+        assert pipe._graph is not None
+        again = _call(pipe, inp, backend.device, N, steps, h, w)       # replay of the captured graph: history slots re-zeroed
+        assert torch.equal(again, fused)
+    with pytest.raises(ValueError):   # a scheduler with noise per step has no fused form
+        from pcdms_amd.schedulers import DDPMScheduler
+        _call(Stage2_InpaintDiffusionPipeline(m, DDPMScheduler.from_config(SD21)), inp, backend.device, N, steps, h, w, mode="fused")
 
 
 def test_rescale_noise_cfg_kernel(backend):

@@ -118,3 +118,36 @@ def test_schedulers_vs_oracle(backend):
     ts = torch.tensor([10, 900])
     an = s2.add_noise(x.to(dev), z.to(dev), ts)
     assert torch.allclose(an.cpu(), o2.add_noise(x, z, ts), atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 20])
+def test_unipc_fused_step_kernel_equals_step(backend, n):
+    """``pcdm_unipc_step`` on static history slots + ``coefficient_table`` (the graph-captured form of the shipped driver's
+    scheduler, ref stage2_batchtest_inpaint_model.py:132) == the stateful ``UniPCMultistepScheduler.step`` over whole runs of
+    1 .. 20 steps (order ramp-up 1 -> 2, corrector from step 1, ``lower_order_final`` at the end), with CFG folded in."""
+    from pcdms_amd import ops
+    dev = backend.device
+    g = torch.Generator().manual_seed(5 + n)
+    shape = (2, 4, 4, 6)
+    x0 = torch.randn(shape, generator=g)
+    eps_all = [torch.randn((4, 4, 4, 6), generator=g) for _ in range(n)]     # [uncond | cond] halves
+    gs = 2.0
+    ref_s = UniPCMultistepScheduler.from_config(SD21)
+    ref_s.set_timesteps(n)
+    x = x0.to(dev)
+    for i, t in enumerate(ref_s.timesteps):
+        e = eps_all[i].to(dev)
+        guided = e[:2] + gs * (e[2:] - e[:2])
+        x = ref_s.step(guided.contiguous(), t, x, return_dict=False)[0]
+    fs = UniPCMultistepScheduler.from_config(SD21)
+    fs.set_timesteps(n)
+    coef = fs.coefficient_table(device=dev)
+    assert coef.shape == (n, 12)
+    lat = x0.clone().to(dev)
+    m1, m2, last = (torch.zeros(shape, device=dev) for _ in range(3))
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    for i in range(n):
+        ops.unipc_step(eps_all[i].to(dev).contiguous(), True, gs, lat, m1, m2, last, coef, step)
+        ops.advance_step(step)
+    backend.sync()
+    assert torch.allclose(lat.cpu(), x.cpu(), rtol=2e-5, atol=2e-5 * float(x.abs().max())), (lat.cpu() - x.cpu()).abs().max()
