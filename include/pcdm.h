@@ -132,7 +132,8 @@ int pcdm_small_linear(const float* x, const void* w, const float* bias, const fl
 
 /* ---- P-2 input assembly: cat([cat([latents]*2), mask, masked_latents], 1) (stage2_inpaint_pipeline.py:499-501)
  * -> NHWC bf16 [Bout, h, w, cpad] with channels >= 9 zero.  latents fp32 NCHW [N,4,h,w]; Bout = rep*N rows
- * (rep = 2 with CFG); mask fp32 [1|Bout,1,h,w]; masked fp32 [1|Bout,4,h,w] (batch-broadcast when *_b == 1). */
+ * (rep = 2 with CFG); mask fp32 [1|Bout,1,h,w]; masked fp32 [1|Bout,4,h,w] (batch-broadcast when *_b == 1).
+ * mask == NULL: the 8-channel stage-3 input cat([latents, gen_t_img_latents], 1) (stage3_refined_pipeline.py:538). */
 int pcdm_assemble_input(const float* latents, int N, int rep, const float* mask, int mask_b, const float* masked,
                         int masked_b, void* out, int h, int w, int cpad, pcdm_stream_t s);
 /* NCHW fp32 -> NHWC bf16 (pose feature st_pose_f, ref :430-431) and back. */
@@ -161,6 +162,10 @@ int pcdm_unipc_step(const float* eps, int cfg, float g, float* x, float* m1, flo
  * x_prev = (c_x0*x0 + c_x*x + c_noise*noise) * out_scale + out_shift.  x_prev may alias x. */
 int pcdm_unclip_step(const float* pred, int cfg, float g, const float* x, const float* noise, float* x_prev,
                      const float* c8, int64_t n, pcdm_stream_t s);
+/* The same step with its eight coefficients read from row *step_dev of a DEVICE table coef[steps][8] and its noise from slab *step_dev
+ * of noise_all [steps, n] (NULL: none), updating x in place: one captured hipGraph serves every step of the stage-1 loop. */
+int pcdm_unclip_step_dev(const float* pred, int cfg, float g, float* x, const float* noise_all, const float* coef,
+                         const int32_t* step_dev, int64_t n, pcdm_stream_t s);
 /* rescale_noise_cfg (stage2_inpaint_pipeline.py:52-63): out = gr * cfg * std(text)/std(cfg) + (1-gr) * cfg, per sample
  * over n = C*H*W elements (unbiased std); cfg_eps / text_eps / out fp32 [N, n]; out may alias cfg_eps. */
 int pcdm_rescale_noise_cfg(const float* cfg_eps, const float* text_eps, float* out, int N, int64_t n,

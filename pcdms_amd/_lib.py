@@ -64,6 +64,7 @@ _SIGS = {
     "pcdm_cfg_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
     "pcdm_unipc_step": ([_P, _I, _F, _P, _P, _P, _P, _P, _P, _L, _P], C.c_int),
     "pcdm_unclip_step": ([_P, _I, _F, _P, _P, _P, C.POINTER(_F), _L, _P], C.c_int),
+    "pcdm_unclip_step_dev": ([_P, _I, _F, _P, _P, _P, _P, _L, _P], C.c_int),
     "pcdm_lincomb": ([_P, _I, C.POINTER(_P), C.POINTER(_F), _L, _P], C.c_int),
     "pcdm_rescale_noise_cfg": ([_P, _P, _P, _I, _L, _F, _P], C.c_int),
     "pcdm_softmax_rows": ([_P, _P, _I, _I, _L, _L, _F, _P], C.c_int),

@@ -84,9 +84,10 @@ __global__ void assemble_input_kernel(const float* __restrict__ latents, int N, 
     for (int e = 0; e < 8; ++e) {
         const int c = oc * 8 + e;
         float v = 0.f;
+        const int c0 = mask ? 5 : 4;   // no mask channel: [latents | masked] (the stage-3 refinement input)
         if (c < 4) v = latents[((int64_t)(b % N) * 4 + c) * HW + pix];
-        else if (c == 4) v = mask[(int64_t)(mask_b == 1 ? 0 : b) * HW + pix];
-        else if (c < 9) v = masked[((int64_t)(masked_b == 1 ? 0 : b) * 4 + (c - 5)) * HW + pix];
+        else if (mask && c == 4) v = mask[(int64_t)(mask_b == 1 ? 0 : b) * HW + pix];
+        else if (c >= c0 && c < c0 + 4) v = masked[((int64_t)(masked_b == 1 ? 0 : b) * 4 + (c - c0)) * HW + pix];
         o[e] = f2bf(v);
     }
     *(u16x8*)(out + i * 8) = o;
@@ -182,6 +183,24 @@ __global__ void unclip_step_kernel(const float* __restrict__ pred, int cfg, floa
     float v = a.c[3] * x0 + a.c[4] * xi;
     if (noise) v += a.c[5] * noise[i];
     x_prev[i] = v * a.c[6] + a.c[7];
+}
+
+// the same with the step's eight coefficients and its noise slab taken from DEVICE tables at *step_dev (hipGraph-replayable stage-1 loop)
+__global__ void unclip_step_dev_kernel(const float* __restrict__ pred, int cfg, float g, float* __restrict__ x,
+                                       const float* __restrict__ noise_all, const float* __restrict__ coef,
+                                       const int32_t* __restrict__ step_dev, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int st = *step_dev;
+    const float* c = coef + 8 * st;
+    float e = pred[i];
+    if (cfg) e = e + g * (pred[n + i] - e);
+    const float xi = x[i];
+    float x0 = c[0] * xi + c[1] * e;
+    if (c[2] > 0.f) x0 = fminf(fmaxf(x0, -c[2]), c[2]);
+    float v = c[3] * x0 + c[4] * xi;
+    if (noise_all && c[5] != 0.f) v += c[5] * noise_all[(int64_t)st * n + i];
+    x[i] = v * c[6] + c[7];
 }
 
 struct LinArgs {
@@ -338,7 +357,7 @@ extern "C" int pcdm_small_linear(const float* x, const void* w, const float* bia
 extern "C" int pcdm_assemble_input(const float* latents, int N, int rep, const float* mask, int mask_b,
                                    const float* masked, int masked_b, void* out, int h, int w, int cpad,
                                    pcdm_stream_t s) {
-    if (!latents || !mask || !masked || !out || N <= 0 || rep <= 0 || cpad % 8 || cpad < 16) return -1;
+    if (!latents || !masked || !out || N <= 0 || rep <= 0 || cpad % 8 || cpad < 16) return -1;   // mask == NULL: [latents | masked]
     const int64_t total = (int64_t)N * rep * h * w * (cpad / 8);
     PCDM_LAUNCH(assemble_input_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, latents, N, rep, mask, mask_b,
                 masked, masked_b, (u16*)out, h * w, cpad);
@@ -392,6 +411,14 @@ extern "C" int pcdm_unclip_step(const float* pred, int cfg, float g, const float
     UnclipArgs a;
     for (int i = 0; i < 8; ++i) a.c[i] = c8[i];
     PCDM_LAUNCH(unclip_step_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, pred, cfg, g, x, noise, x_prev, a, n);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_unclip_step_dev(const float* pred, int cfg, float g, float* x, const float* noise_all, const float* coef,
+                                    const int32_t* step_dev, int64_t n, pcdm_stream_t s) {
+    if (!pred || !x || !coef || !step_dev || n <= 0) return -1;
+    PCDM_LAUNCH(unclip_step_dev_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)s, pred, cfg, g, x, noise_all, coef, step_dev, n);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

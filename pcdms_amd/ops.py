@@ -435,12 +435,15 @@ def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
-def assemble_input(latents: torch.Tensor, rep: int, mask: torch.Tensor, masked: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """latents fp32 [N,4,h,w]; mask [1|rep*N,1,h,w]; masked [1|rep*N,4,h,w] -> out bf16 [rep*N,h,w,cpad]."""
+def assemble_input(latents: torch.Tensor, rep: int, mask: Optional[torch.Tensor], masked: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """latents fp32 [N,4,h,w]; mask [1|rep*N,1,h,w] or None (no mask channel: stage 3); masked [1|rep*N,4,h,w]
+    -> out bf16 [rep*N,h,w,cpad]."""
     N, _, h, w = latents.shape
-    _c(latents, torch.float32); _c(mask, torch.float32); _c(masked, torch.float32); _c(out, BF16)
+    _c(latents, torch.float32); _c(masked, torch.float32); _c(out, BF16)
+    if mask is not None:
+        _c(mask, torch.float32)
     cpad = out.shape[-1]
-    _chk(_lib.lib().pcdm_assemble_input(_ptr(latents), N, rep, _ptr(mask), mask.shape[0], _ptr(masked),
+    _chk(_lib.lib().pcdm_assemble_input(_ptr(latents), N, rep, _ptr(mask), 1 if mask is None else mask.shape[0], _ptr(masked),
                                         masked.shape[0], _ptr(out), h, w, cpad, _stream(out)), "pcdm_assemble_input")
     return out
 
@@ -503,6 +506,18 @@ def unclip_step(pred: torch.Tensor, cfg: bool, g: float, x: torch.Tensor, noise:
     _chk(_lib.lib().pcdm_unclip_step(_ptr(pred), int(cfg), float(g), _ptr(x), _ptr(noise), _ptr(out), carr, n, _stream(x)),
          "pcdm_unclip_step")
     return out
+
+
+def unclip_step_dev(pred: torch.Tensor, cfg: bool, g: float, x: torch.Tensor, noise_all: Optional[torch.Tensor], coef: torch.Tensor,
+                    step_dev: torch.Tensor) -> None:
+    """pcdm_unclip_step_dev: in place on x; coef fp32 [steps, 8], noise_all fp32 [steps, x.numel()] (or None), both on the device."""
+    _c(pred, torch.float32); _c(x, torch.float32); _c(coef, torch.float32)
+    n = x.numel()
+    assert pred.numel() == (2 * n if cfg else n) and coef.shape[-1] == 8
+    if noise_all is not None:
+        assert _c(noise_all, torch.float32).numel() == coef.shape[0] * n
+    _chk(_lib.lib().pcdm_unclip_step_dev(_ptr(pred), int(cfg), float(g), _ptr(x), _ptr(noise_all), _ptr(coef), _ptr(step_dev), n,
+                                         _stream(x)), "pcdm_unclip_step_dev")
 
 
 def lincomb(out: torch.Tensor, xs: Sequence[torch.Tensor], cs: Sequence[float]) -> torch.Tensor:

@@ -230,7 +230,7 @@ class Stage2_InpaintDiffusionPipeline:
                 x = torch.cat([lat] * 2) if do_cfg else lat
                 x = self.scheduler.scale_model_input(x, t)
                 B = x.shape[0]
-                inp = torch.cat([x, mask.expand(B, -1, -1, -1), masked.expand(B, -1, -1, -1)], dim=1)
+                inp = torch.cat([x] + ([] if mask is None else [mask.expand(B, -1, -1, -1)]) + [masked.expand(B, -1, -1, -1)], dim=1)
                 eps = self.unet(inp, t, class_labels=prior_embed, encoder_hidden_states=feature_f,
                                 my_pose_cond=pose_cond, return_dict=False)[0]
                 if do_cfg:
@@ -302,12 +302,12 @@ class Stage2_InpaintDiffusionPipeline:
         B = rep * N
         n0 = N if (do_cfg and zero_uncond) else 0
         unipc = isinstance(self.scheduler, UniPCMultistepScheduler)
-        key = (B, h, w, n, rep, n0, tuple(feature_f.shape), tuple(mask.shape), tuple(masked.shape), tuple(pose_cond.shape),
-               prior_embed is None, unipc)
+        key = (B, h, w, n, rep, n0, tuple(feature_f.shape), None if mask is None else tuple(mask.shape), tuple(masked.shape),
+               None if pose_cond is None else tuple(pose_cond.shape), prior_embed is None, unipc)
         st = self._st if self._graph_key == key else {}
         if not st:
             st.update(B=B, h=h, w=w, rep=rep, unipc=unipc,
-                      lat=torch.empty_like(lat), mask=torch.empty_like(mask), masked=torch.empty_like(masked),
+                      lat=torch.empty_like(lat), mask=None if mask is None else torch.empty_like(mask), masked=torch.empty_like(masked),
                       eps_g=torch.empty_like(lat),
                       x_in=torch.empty(B, h, w, 64, dtype=ops.BF16, device=dev),
                       step=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -322,7 +322,8 @@ class Stage2_InpaintDiffusionPipeline:
         # (a reference-mode call, a bare unet(...)) left in those shared buffers is overwritten, and the graph only ever reads
         # the same addresses.
         st["lat"].copy_(lat)
-        st["mask"].copy_(mask)
+        if mask is not None:
+            st["mask"].copy_(mask)
         st["masked"].copy_(masked)
         st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
         st["timesteps"].copy_(timesteps.to(dev))
@@ -393,7 +394,7 @@ class Stage3_RefinedDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
                  latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "pil", return_dict: bool = True,
                  callback=None, callback_steps: int = 1, guidance_rescale: float = 0.0,
                  vae_gen_t_image: Optional[torch.Tensor] = None, s_img_proj_f: Optional[torch.Tensor] = None,
-                 gen_t_img_latents: Optional[torch.Tensor] = None):
+                 gen_t_img_latents: Optional[torch.Tensor] = None, mode: Optional[str] = None, use_graph: bool = True):
         device = self.device
         N = num_images_per_prompt
         f32 = dict(device=device, dtype=torch.float32)
@@ -410,24 +411,12 @@ class Stage3_RefinedDiffusionPipeline(Stage2_InpaintDiffusionPipeline):
             gl = torch.cat([torch.zeros_like(gl), gl])
         feat, gl = feat.contiguous(), gl.contiguous()
         self.scheduler.set_timesteps(num_inference_steps, device=device)
-        lat = self.prepare_latents(s_img_proj_f.shape[0] * N, 4, height, width, torch.float32, device, generator, latents)
+        lat = self.prepare_latents(s_img_proj_f.shape[0] * N, 4, height, width, torch.float32, device, generator, latents).contiguous()
         extra = self.prepare_extra_step_kwargs(generator, eta)
-        self.unet.invalidate_caches()   # (bare unet(...) calls below: see Stage2_InpaintDiffusionPipeline._sample)
-        for i, t in enumerate(self.scheduler.timesteps):
-            x = torch.cat([lat] * 2) if do_cfg else lat
-            x = self.scheduler.scale_model_input(x, t)
-            eps = self.unet(torch.cat([x, gl], dim=1), t, encoder_hidden_states=feat, return_dict=False)[0]
-            if do_cfg:
-                g = torch.empty_like(lat)
-                eps = eps.float().contiguous()
-                ops.cfg_step(eps, True, float(guidance_scale), None, None, None, eps_out=g)
-                if guidance_rescale > 0.0:
-                    g = rescale_noise_cfg(g, eps[eps.shape[0] // 2:], guidance_rescale)
-                eps = g
-            lat = self.scheduler.step(eps, t, lat, **extra, return_dict=False)[0]
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, lat)
-        self.unet.invalidate_caches()
+        # the same loop machinery as stage 2 (ref :533-563): no mask channel, no pose, no class labels; DDIM / UniPC run as the
+        # captured fused step, anything else through the literal loop
+        lat = self._sample(lat, None, gl, None, feat, None, self.scheduler.timesteps, do_cfg, guidance_scale, guidance_rescale, eta, extra,
+                           mode, use_graph, callback, callback_steps, zero_uncond=do_cfg)
         images = self._postprocess(lat, output_type)
         if not return_dict:
             return (images, None)

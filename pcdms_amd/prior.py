@@ -174,6 +174,7 @@ class Stage1_PriorTransformer(_HipModule):
     # ---------------------------------------------------------------- packing
     def _pack(self):
         self._ready()
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1   # (a captured hipGraph holds pointers into the packed weights)
         sd, dev, D = self._sd, self._device, self.inner_dim
 
         def f32(k):
@@ -238,7 +239,7 @@ class Stage1_PriorTransformer(_HipModule):
     @torch.no_grad()
     def forward(self, hidden_states, timestep: Union[torch.Tensor, float, int], proj_embedding, encoder_hidden_states,
                 encoder_hidden_states1, attention_mask=None, return_dict: bool = True,
-                do_classifier_free_guidance: bool = False, test_flag: bool = False):
+                do_classifier_free_guidance: bool = False, test_flag: bool = False, _step_dev: Optional[torch.Tensor] = None):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask: the reference's only call site passes None (stage1_prior_pipeline.py:464)")
         if test_flag:
@@ -251,16 +252,19 @@ class Stage1_PriorTransformer(_HipModule):
         w, c, D, E, T = self._w, self.config, self.inner_dim, self.config.embedding_dim, self.num_tokens
         B = hidden_states.shape[0]
         M = B * T
-        if torch.is_tensor(timestep):
-            tv = timestep.reshape(-1)
-            if tv.numel() > 1 and not bool((tv == tv[0]).all()):
-                raise NotImplementedError("per-row timesteps")
-            timestep = tv[0].item()
-        t_dev = torch.tensor([int(timestep)], dtype=torch.int64, device=self._device)
+        if _step_dev is not None:   # captured loop: ``timestep`` is the device table of all timesteps, indexed by the device step counter
+            t_dev = timestep
+        else:
+            if torch.is_tensor(timestep):
+                tv = timestep.reshape(-1)
+                if tv.numel() > 1 and not bool((tv == tv[0]).all()):
+                    raise NotImplementedError("per-row timesteps")
+                timestep = tv[0].item()
+            t_dev = torch.tensor([int(timestep)], dtype=torch.int64, device=self._device)
         tokens = self._buf("tokens", (M, D))
         self._static_tokens(tokens, proj_embedding, encoder_hidden_states, encoder_hidden_states1, B)
         # time token: sinusoid -> Linear+SiLU -> Linear (+ positional row 3)
-        sin = ops.timestep_embedding(t_dev, None, self._buf("sin", (B, D), torch.float32), flip=True, shift=0.0)
+        sin = ops.timestep_embedding(t_dev, _step_dev, self._buf("sin", (B, D), torch.float32), flip=True, shift=0.0)
         th = ops.gemm(ops.f32_to_bf16(sin, self._buf("sinb", (B, D))), w["t1"], self._buf("th", (B, D)), act=ops.ACT_SILU)
         ops.gemm(th, w["t2"], self._token(tokens, 3), residual=w["pos"][3:4], res_mod=1)
         # x_t token
@@ -354,6 +358,53 @@ class Stage1_PriorPipeline:
             raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
         return (latents.to(device, torch.float32) * scheduler.init_noise_sigma).contiguous()
 
+    def _run_graph(self, x, emb, sp, tp, ts, rows, noises, cfg_on, g):
+        """The denoise loop (ref :453-483) as ONE captured step replayed ``len(ts)`` times: prior forward (timestep from a device
+        table at the device step counter) -> ``pcdm_unclip_step_dev`` (CFG + scheduler step, coefficients and noise from device
+        tables) -> ``pcdm_advance_step``.  ~150 launches of a few microseconds each per step otherwise pay the host's launch rate."""
+        dev, prior = x.device, self.prior
+        n = len(ts)
+        key = (tuple(x.shape), tuple(emb.shape), n, cfg_on, g, id(prior), getattr(prior, "_pack_gen", 0))
+        st = getattr(self, "_gst", None)
+        if st is None or st["key"] != key:
+            st = dict(key=key, x=torch.empty_like(x), emb=torch.empty_like(emb), sp=torch.empty_like(sp), tp=torch.empty_like(tp),
+                      ts=torch.empty(n, dtype=torch.int64, device=dev), coef=torch.empty(n, 8, dtype=torch.float32, device=dev),
+                      noise=torch.empty(n, x.numel(), dtype=torch.float32, device=dev),
+                      step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None)
+            self._gst = st
+        st["x"].copy_(x); st["emb"].copy_(emb); st["sp"].copy_(sp); st["tp"].copy_(tp)
+        st["ts"].copy_(torch.tensor(ts, dtype=torch.int64))
+        st["coef"].copy_(torch.tensor(rows, dtype=torch.float32))
+        st["noise"].copy_(torch.stack([z.reshape(-1) for z in noises]))
+        st["step"].zero_()
+
+        def step():
+            xin = torch.cat([st["x"], st["x"]]) if cfg_on else st["x"]
+            pred = prior(xin.unsqueeze(1), timestep=st["ts"], proj_embedding=st["emb"], encoder_hidden_states=st["sp"],
+                         encoder_hidden_states1=st["tp"], attention_mask=None, _step_dev=st["step"]).predicted_image_embedding
+            ops.unclip_step_dev(pred, cfg_on, g, st["x"], st["noise"], st["coef"], st["step"])
+            ops.advance_step(st["step"])
+        # the step-invariant tokens (poses, image embedding) are refreshed eagerly from this call's tensors; the captured step then
+        # finds them cached (same static tensors, same versions) and contains only the per-step kernels
+        prior._static = None
+        if st["graph"] is None or st.get("ws_gen") != ops.workspace_generation(dev):
+            x0 = st["x"].clone()
+            step()                                    # warm-up: allocates scratch, autotunes unseen GEMM shapes
+            torch.cuda.synchronize()
+            st["x"].copy_(x0); st["step"].zero_()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                step()
+            st["x"].copy_(x0); st["step"].zero_()
+            st["graph"], st["ws_gen"] = graph, ops.workspace_generation(dev)
+        else:
+            step_tokens = prior._static_tokens        # (eager refresh of tokens 0-2 for this call's conditioning)
+            B = (2 if cfg_on else 1) * x.shape[0]
+            step_tokens(prior._buf("tokens", (B * prior.num_tokens, prior.inner_dim)), st["emb"], st["sp"], st["tp"], B)
+        for _ in range(n):
+            st["graph"].replay()
+        return st["x"].clone()
+
     def get_zero_embed(self, batch_size=1, device=None):
         if self.image_encoder is None:
             return None
@@ -365,7 +416,7 @@ class Stage1_PriorPipeline:
     def __call__(self, s_embed, s_pose, t_pose, negative_prompt=None, num_images_per_prompt: int = 1,
                  num_inference_steps: int = 25, generator=None, latents=None, guidance_scale: float = 4.0,
                  output_type: Optional[str] = "pt", return_dict: bool = True,
-                 variance_noises: Optional[Sequence[torch.Tensor]] = None):
+                 variance_noises: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True):
         if output_type not in ("pt", "np"):
             raise ValueError(f"Only the output types `pt` and `np` are supported not output_type={output_type}")
         if s_embed.shape[0] != 1:
@@ -382,22 +433,31 @@ class Stage1_PriorPipeline:
         ts = [int(t) for t in self.scheduler.timesteps.tolist()]
         E = self.prior.config.embedding_dim
         x = self.prepare_latents((N, E), torch.float32, dev, generator, latents, self.scheduler)
+        n = len(ts)
+        # per-step scalars and noise, all known before the loop (the noise is drawn in the same order the reference's loop would)
+        rows, noises = [], []
         for i, t in enumerate(ts):
-            xin = torch.cat([x, x]) if cfg_on else x
-            pred = self.prior(xin.unsqueeze(1), timestep=t, proj_embedding=emb, encoder_hidden_states=sp,
-                              encoder_hidden_states1=tp, attention_mask=None).predicted_image_embedding
-            last = i + 1 == len(ts)
+            last = i + 1 == n
             co = self.scheduler.step_coefficients(t, None if last else ts[i + 1])
-            noise = None
+            rows.append((*co, CLIP_STD if last else 1.0, CLIP_MEAN if last else 0.0))   # post_process_latents (:485) folded into the last step
             if co[5] > 0:
                 if variance_noises is not None:
-                    noise = variance_noises[i].to(dev, torch.float32).contiguous()
+                    noises.append(variance_noises[i].to(dev, torch.float32).reshape(N, E))
                 else:
                     gdev = generator.device if isinstance(generator, torch.Generator) else dev
-                    noise = torch.randn((N, E), generator=generator, device=gdev, dtype=torch.float32).to(dev)
-            # CFG combine (:467-471) + UnCLIPScheduler.step (:478-483); post_process_latents (:485) folded into the last step
-            x = ops.unclip_step(pred, cfg_on, float(guidance_scale), x, noise, torch.empty_like(x),
-                                (*co, CLIP_STD if last else 1.0, CLIP_MEAN if last else 0.0))
+                    noises.append(torch.randn((N, E), generator=generator, device=gdev, dtype=torch.float32).to(dev))
+            else:
+                noises.append(torch.zeros(N, E, device=dev))
+        if use_graph and dev.type == "cuda":
+            x = self._run_graph(x, emb, sp, tp, ts, rows, noises, cfg_on, float(guidance_scale))
+        else:
+            for i, t in enumerate(ts):
+                xin = torch.cat([x, x]) if cfg_on else x
+                pred = self.prior(xin.unsqueeze(1), timestep=t, proj_embedding=emb, encoder_hidden_states=sp,
+                                  encoder_hidden_states1=tp, attention_mask=None).predicted_image_embedding
+                # CFG combine (:467-471) + UnCLIPScheduler.step (:478-483)
+                x = ops.unclip_step(pred, cfg_on, float(guidance_scale), x, noises[i].contiguous() if rows[i][5] > 0 else None,
+                                    torch.empty_like(x), rows[i])
         image_embeddings = x
         if negative_prompt is None:
             zero_embeds = self.get_zero_embed(x.shape[0], device=dev)

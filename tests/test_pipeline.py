@@ -208,6 +208,12 @@ def test_stage3_refine_pipeline(gpu_backend):
     out = pipe(height=h * 8, width=w * 8, gen_t_img_latents=gl.to(dev), s_img_proj_f=feat.to(dev), latents=lat.to(dev),
                num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent").latents
     assert _rel(out, ref) <= 3e-2, _rel(out, ref)
+    # default mode = the captured fused step (8-channel input assembly without a mask channel, UniPC device table); it must agree
+    # with the reference's literal loop (ref stage3_refined_pipeline.py:533-563) on the same kernels
+    assert pipe._graph is not None
+    lit = pipe(height=h * 8, width=w * 8, gen_t_img_latents=gl.to(dev), s_img_proj_f=feat.to(dev), latents=lat.to(dev),
+               num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent", mode="reference").latents
+    assert _rel(lit, ref) <= 3e-2 and _same_path(out, lit)
 
 
 @pytest.mark.gpu

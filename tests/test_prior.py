@@ -140,6 +140,19 @@ def test_prior_pipeline(backend):
     got = pipe(s_embed=t("s_embed"), s_pose=t("s_pose"), t_pose=t("t_pose"), num_images_per_prompt=2, num_inference_steps=5,
                latents=lat, guidance_scale=2.5, variance_noises=noises, return_dict=False)[0]
     assert _rel(got, ref) <= 3e-2, _rel(got, ref)
+    # the default path on the GPU is ONE captured step replayed 5 times (device timestep / coefficient / noise tables); it must agree
+    # with the literal loop, and a second pair through the SAME graph (different conditioning and latents) with its own eager run
+    assert pipe._gst["graph"] is not None
+    kw = dict(num_images_per_prompt=2, num_inference_steps=5, guidance_scale=2.5, variance_noises=noises, return_dict=False)
+    eager = pipe(s_embed=t("s_embed"), s_pose=t("s_pose"), t_pose=t("t_pose"), latents=lat, use_graph=False, **kw)[0]
+    assert _rel(got, eager.cpu()) <= 1e-3, _rel(got, eager.cpu())
+    graph_obj = pipe._gst["graph"]
+    e2, sp2, tp2, lat2 = t("s_embed") * 0.5 + 0.1, t("t_pose"), t("s_pose"), torch.randn(2, 1024, generator=g)
+    b_graph = pipe(s_embed=e2, s_pose=sp2, t_pose=tp2, latents=lat2, **kw)[0]
+    assert pipe._gst["graph"] is graph_obj
+    b_eager = pipe(s_embed=e2, s_pose=sp2, t_pose=tp2, latents=lat2, use_graph=False, **kw)[0]
+    assert _rel(b_graph, b_eager.cpu()) <= 1e-3, _rel(b_graph, b_eager.cpu())
+    assert _rel(b_graph, got.cpu()) > 1e-2     # (and it is a different result: the conditioning was refreshed)
 
 
 @pytest.mark.gpu
