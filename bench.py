@@ -189,6 +189,10 @@ def main():
         result["roofline"] = kernel_roofline(pipe, ops, dinp, N, h, w)
         # whole-path fraction of the MFMA roof beside the dominant family's (un-hoisted algorithmic FLOPs, see config.flops_note)
         result["roofline"]["e2e_frac"] = round(e2e_tflops / PEAK_BF16_TFLOPS, 4)
+        # the same with the FLOPs the kernels actually execute (K/V hoisting and the CFG cross-attention skip taken out)
+        ex_tflops = result["roofline"]["executed_gflop_per_denoise_step"] * 1e9 * args.ddim_steps * args.steps / elapsed / 1e12
+        result["roofline"]["e2e_frac_executed"] = round(ex_tflops / PEAK_BF16_TFLOPS, 4)
+        result["config"]["e2e_tflops_per_gpu_executed"] = round(ex_tflops, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(sd, cfg, inp, N, args.ddim_steps)
     if use_dist:
@@ -276,10 +280,11 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
     assert len({len(r) for r in reps}) == 1
     log = []
     for entries in zip(*reps):
-        name, flops, _, _, info = entries[0]
-        log.append((name, flops, min(a.elapsed_time(b) for _, _, a, b, _ in entries), info))
+        name, flops, info = entries[0][0], entries[0][1], entries[0][4]
+        log.append((name, flops, min(e[2].elapsed_time(e[3]) for e in entries), info))
     fam = {}
     tiles = {}
+    executed = sum(ex for _, _, _, _, _, ex in (e if len(e) > 5 else (*e, e[1]) for e in reps[0]))   # FLOPs actually issued in one step
     for name, flops, ms, info in log:
         if name == "gemm_kernel":
             tiles[info[-2]] = tiles.get(info[-2], 0) + 1
@@ -289,16 +294,23 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
         f[2] += ms * 1e-3
     gk = fam["gemm_kernel"]
     achieved = gk[1] / gk[2] / 1e12
-    traffic = None
-    tj = ROOT / "profiles" / "gemm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (offline; see file)
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes are separate runs (tools/pmc_traffic.py): the figure is quoted only while the
+    # kernel sources it was measured on are the ones in this tree (hash recorded by the tool), never silently stale
+    traffic, traffic_note = None, "no PMC traffic file"
+    tj = ROOT / "profiles" / "gemm_traffic.json"
     if tj.exists():
-        traffic = json.loads(tj.read_text()).get("hbm_bytes_per_launch")
+        tdoc = json.loads(tj.read_text())
+        if tdoc.get("kernel_src_sha256") == kernel_source_hash():
+            traffic, traffic_note = tdoc.get("hbm_bytes_per_launch"), f"profiles/gemm_traffic.json ({tdoc.get('measured', 'rocprofv3 --pmc')})"
+        else:
+            traffic_note = "profiles/gemm_traffic.json was measured on other kernel sources (hash mismatch): not quoted"
     out = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+           "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
            "kernel": "gemm_kernel<BM,BN,CONV> (implicit-GEMM conv3x3 + linear, all instances)",
            "launches_per_denoise_step": gk[0], "avg_launch_us": round(gk[2] / gk[0] * 1e6, 2),
            "alg_gflop_per_launch": round(gk[1] / gk[0] / 1e9, 2),
            "tile_configs_used": {str(k): v for k, v in sorted(tiles.items())},
+           "executed_gflop_per_denoise_step": round(executed / 1e9, 1),
            "note": "HIP events around each launch of one eager denoise step enqueued behind a spin kernel, per-launch min of 3 (UNet batch %d, latent %dx%d)" % (2 * N, h, w)}
     if "flash_attn_kernel" in fam:
         fa = fam["flash_attn_kernel"]
@@ -317,6 +329,16 @@ def kernel_roofline(pipe, ops, dinp, N, h, w):
     return out
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP kernel sources + headers libpcdm.so is built from (what a PMC measurement is valid for)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted((ROOT / "pcdms_amd" / "csrc").glob("*")) + [ROOT / "include" / "pcdm.h"]:
+        if f.is_file():
+            hsh.update(f.name.encode()); hsh.update(f.read_bytes())
+    return hsh.hexdigest()
+
+
 def cpu_baseline(sd, cfg, inp, N, ddim_steps):
     """The fp32 PyTorch CPU restatement (oracle/) timed on this box's host cores.  Substitute for the reference's CPU diffusers
     path, which cannot run (diffusers is not installed / vendored).  Two records:
@@ -327,31 +349,77 @@ def cpu_baseline(sd, cfg, inp, N, ddim_steps):
     from oracle.pipeline import build_conditioning, stage2_sample, synth_inputs
     from oracle.schedulers import DDIMOracle
     from oracle.unet import unet_forward
-    cores = torch.get_num_threads()
+    topo = host_topology()
     c = build_conditioning(inp["masked_latents"], inp["s_img_proj_f"], inp["st_pose_f"], inp["pred_t_img_embed"], N, True)
     sch = DDIMOracle()
     sch.set_timesteps(ddim_steps)
     lat = inp["latents"].clone()
-    with torch.no_grad():
-        # configs[0] first: it also warms the host thread pool / primitive caches for the full-size step that follows
-        inp1 = synth_inputs(cfg, 32, 64, 1)
-        t0 = time.perf_counter()
-        out1 = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=1, guidance_scale=2.0, num_inference_steps=20, **inp1)
-        c1_s = time.perf_counter() - t0
+    threads_before = torch.get_num_threads()
+    # thread counts to time: the PHYSICAL cores of one socket, and of the whole box.  torch's default is the number of
+    # LOGICAL CPUs (round 2 timed 128 threads on a 2 x 32-core box: hyper-threads and the second socket's memory made the fp32 GEMMs
+    # ~4x slower than 8 threads on 8 cores).  `value` / `cores` are the better of the two.
+    counts = sorted({topo["cores_per_socket"], topo["physical_cores"]})
+
+    def one_step(nthreads):
+        torch.set_num_threads(nthreads)
         t = sch.timesteps[0]
         t0 = time.perf_counter()
         x = torch.cat([lat] * 2)
         eps = unet_forward(sd, cfg, torch.cat([x, c["mask"], c["masked_latents"]], 1), t, c["feature_f"],
                            c["prior_embed"], c["pose_cond"])
         u, cn = eps.chunk(2)
-        lat = sch.step(u + 2.0 * (cn - u), t, lat)
-        per_step = time.perf_counter() - t0
+        out = sch.step(u + 2.0 * (cn - u), t, lat)
+        assert torch.isfinite(out).all()
+        return time.perf_counter() - t0
+    with torch.no_grad():
+        # configs[0] first: it also warms the host thread pool / primitive caches for the full-size step that follows
+        torch.set_num_threads(counts[0])
+        inp1 = synth_inputs(cfg, 32, 64, 1)
+        t0 = time.perf_counter()
+        out1 = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=1, guidance_scale=2.0, num_inference_steps=20, **inp1)
+        c1_s = time.perf_counter() - t0
+        per = {n: one_step(n) for n in counts}
+    torch.set_num_threads(threads_before)
     assert torch.isfinite(out1).all()
-    return {"value": round(N / (per_step * ddim_steps), 5), "unit": "images/s", "cores": cores, "kind": "port",
+    best = min(per, key=per.get)
+    per_step = per[best]
+    return {"value": round(N / (per_step * ddim_steps), 5), "unit": "images/s", "cores": best, "kind": "port",
             "sample": f"1 timed denoise step (after the configs[0] run as warm-up) of the same workload (UNet batch {2 * N}, fp32, "
-                      f"torch {torch.__version__} CPU ops), {per_step:.2f} s/step, extrapolated x{ddim_steps}",
+                      f"torch {torch.__version__} CPU ops) per thread count, {per_step:.2f} s/step at {best} threads, extrapolated x{ddim_steps}",
+            "host": topo,
+            "per_thread_count": {str(n): {"s_per_step": round(v, 2), "images_per_s": round(N / (v * ddim_steps), 5),
+                                          "tflops_fp32": round(2 * N * FLOP_PER_ROW_FWD / v / 1e12, 3)} for n, v in per.items()},
             "config1": {"workload": "configs[0]: 1 pair 256x256 (latent 32x64), N=1, 20 DDIM steps, guidance 2.0, fp32 CPU, full run",
-                        "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}
+                        "threads": counts[0], "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}
+
+
+def host_topology():
+    """Sockets / physical cores / logical CPUs of this host from /proc/cpuinfo (what ``cores`` of the CPU baseline refers to)."""
+    logical = os.cpu_count() or 1
+    cores, sockets = set(), set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core)); sockets.add(phys)
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core)); sockets.add(phys)
+    except OSError:
+        pass
+    n_phys = len(cores) or logical
+    n_sock = len(sockets) or 1
+    try:   # a container may be limited to fewer CPUs than the host shows
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = logical
+    n_phys = max(1, min(n_phys, avail))
+    return {"sockets": n_sock, "physical_cores": n_phys, "cores_per_socket": max(1, n_phys // n_sock), "logical_cpus": logical}
 
 
 if __name__ == "__main__":

@@ -32,8 +32,13 @@ int pcdm_is_emulator(void);
  * skip concat (ref :792-793, K6) is never materialised.  y [B,HW,C1+C2] bf16.
  * ws: fp32 workspace of pcdm_groupnorm_ws_floats(B, C1+C2) floats, ZERO-FILLED once when allocated and written by nothing but
  * pcdm_groupnorm afterwards (its head holds arrival counters that every launch leaves at zero); one workspace may serve calls of
- * any shape with B' <= B on one stream. */
+ * any shape with B' <= B on one stream.
+ * Shapes whose slab is split over several workgroups that exchange statistics inside the launch (UNet levels 0 / 1) rely on those
+ * workgroups being co-resident: the library checks the device (occupancy x CUs, no CU mask) and each workgroup's wait is BOUNDED --
+ * if its partners do not arrive (~50 ms: CUs held by another stream / process) it computes the slab's statistics alone: slower, same
+ * result up to summation order, never a hang.  pcdm_groupnorm_cluster_timeouts reads how often that happened (synchronous). */
 int64_t pcdm_groupnorm_ws_floats(int B, int C);
+int pcdm_groupnorm_cluster_timeouts(const float* ws, unsigned* count_out, pcdm_stream_t s);
 int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
                    const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
 

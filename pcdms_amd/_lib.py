@@ -48,6 +48,7 @@ _SIGS = {
     "pcdm_version": ([], C.c_int),
     "pcdm_is_emulator": ([], C.c_int),
     "pcdm_groupnorm_ws_floats": ([_I, _I], _L),
+    "pcdm_groupnorm_cluster_timeouts": ([_P, C.POINTER(C.c_uint), _P], C.c_int),
     "pcdm_groupnorm": ([_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_layernorm": ([_P, _P, _I, _I, _F, _P, _P, _P], C.c_int),
     "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),

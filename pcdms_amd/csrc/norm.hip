@@ -22,6 +22,7 @@ constexpr int kGnUnroll = 4;   // independent 16-byte loads in flight per thread
                                // 128 chunks x 8 loads was 25 % slower at 64x88 (per-block reduction tail dominates)
 constexpr int kGnMaxC = 4096;
 constexpr int kThreads = 256;
+constexpr unsigned kGnSpinLimit = 400000;   // polls of ~128 cycles (s_sleep 2 + a memory round trip): ~50 ms
 constexpr int kGnClusterMaxWgs = 256;   // one workgroup per CU: every partner of a cluster is resident, whatever the dispatch order
 
 struct GnGeom {
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
                                                             float* __restrict__ ws) {
     __shared__ float red[(THREADS / 64) * 4];
     __shared__ float stat[8];                    // {mean, rstd} of the <= 4 groups of this slab
+    __shared__ int stat_flag[1];                 // 1: the partners did not arrive in time (see the poll)
     const int C = C1 + C2;
     const int nslab = gridDim.x / S;
     const int slab = blockIdx.x % nslab, chunk = blockIdx.x / nslab;   // partners are nslab apart: different XCDs do not matter here
@@ -410,16 +412,50 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     if (t < 8) pcdm_store_sys(part + chunk * 8 + t, (t & 1) ? qg[t >> 1] : sg[t >> 1]);
     pcdm_drain_vmem();
     __syncthreads();
+    // BOUNDED poll: the launcher checked that the grid fits the device (occupancy x CUs), but a plain launch cannot promise co-residency
+    // when something else holds CUs (another stream's long kernel, another process, a CU mask).  A workgroup whose partners have not
+    // arrived within kGnSpinLimit polls (~50 ms) stops waiting and computes the statistics of the WHOLE slab itself (it re-reads the
+    // other chunks' rows: slow, correct, never a hang), and counts the event in ws (pcdm_groupnorm_cluster_timeouts).
     if (t == 0) {
         pcdm_atomic_inc_agent(cnt);
-        while (pcdm_load_sys_u32(cnt) < (unsigned)S) pcdm_sleep();
+        unsigned spins = 0;
+        bool ok = true;
+        while (pcdm_load_sys_u32(cnt) < (unsigned)S) {
+            pcdm_sleep();
+            if (++spins > kGnSpinLimit) { ok = false; break; }
+        }
+        stat_flag[0] = ok ? 0 : 1;
+        if (!ok) pcdm_atomic_inc_agent((unsigned*)(ws + kGnClusterMaxWgs * 8) + kGnClusterMaxWgs * 2);
     }
     __syncthreads();
+    const bool alone = stat_flag[0] != 0;   // block-uniform
+    float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (alone) {
+        for (int r = rp; r < HW && active; r += rows_par) {
+            const u16x8 z = gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(z[e]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    fs[k] += (ge[e] == k) ? f : 0.f;
+                    fq[k] += (ge[e] == k) ? f * f : 0.f;
+                }
+            }
+        }
+        gn_block_sum4<THREADS>(fs, gpb, red);
+        gn_block_sum4<THREADS>(fq, gpb, red);
+    }
     if (t < gpb) {
         double ss = 0.0, qq = 0.0;
-        for (int ch = 0; ch < S; ++ch) {
-            ss += (double)pcdm_load_sys(part + ch * 8 + 2 * t);
-            qq += (double)pcdm_load_sys(part + ch * 8 + 2 * t + 1);
+        if (alone) {
+            ss = (double)(t == 0 ? fs[0] : t == 1 ? fs[1] : t == 2 ? fs[2] : fs[3]);
+            qq = (double)(t == 0 ? fq[0] : t == 1 ? fq[1] : t == 2 ? fq[2] : fq[3]);
+        } else {
+            for (int ch = 0; ch < S; ++ch) {
+                ss += (double)pcdm_load_sys(part + ch * 8 + 2 * t);
+                qq += (double)pcdm_load_sys(part + ch * 8 + 2 * t + 1);
+            }
         }
         const double mean = ss * inv_n;            // (fp64 multiplies only: fp64 divide / sqrt sequences cost ~40 registers here)
         double var = qq * inv_n - mean * mean;
@@ -602,19 +638,44 @@ static bool gn_cluster_enabled() {
     // The partners of a cluster wait for each other inside the launch: every workgroup of the grid must be resident at once.  One
     // 512-thread workgroup per CU always fits, so the condition is a device with at least kGnClusterMaxWgs CUs (a full MI355X has
     // 256; a partitioned one -- CPX mode -- does not, and takes the other paths).  PCDM_GN_CLUSTER=0: A/B switch.
-    static const bool enabled = [] {
+    // Evaluated per DEVICE (a process may drive several): the occupancy query must admit at least one 512-thread workgroup of either
+    // instantiation per CU, and CUs x that >= the largest grid.  A CU mask hides CUs from the dispatcher while the attribute still
+    // reports 256, so any mask in the environment disables the path.  What the query cannot see is OTHER work holding CUs at launch
+    // time (a second stream, another process): the kernel's bounded poll covers that (no hang; INTEGRATION.md states the contract).
+    static int state[64] = {0};   // 0 = unknown, 1 = enabled, 2 = disabled
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0) {
+        bool ok = true;
         const char* e = getenv("PCDM_GN_CLUSTER");
-        if (e && e[0] == '0') return false;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-        return cus >= kGnClusterMaxWgs;
-    }();
-    return enabled;
+        if (e && e[0] == '0') ok = false;
+        for (const char* m : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"})
+            if (getenv(m)) ok = false;
+        int cus = 0, nb8 = 0, nb16 = 0;
+        if (ok && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ok = false;
+        if (ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, gn_cluster_kernel<512, 8>, 512, 0) != hipSuccess ||
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, gn_cluster_kernel<512, 16>, 512, 0) != hipSuccess))
+            ok = false;
+        if (ok && ((int64_t)cus * (nb8 < nb16 ? nb8 : nb16) < kGnClusterMaxWgs || cus < kGnClusterMaxWgs)) ok = false;
+        state[dev] = ok ? 1 : 2;
+    }
+    return state[dev] == 1;
 #endif
 }
 
+// smallest split S (2, 4, 8) of a slab over workgroups that the cluster kernel can take: <= kGnClusterMaxWgs workgroups in total and
+// <= 16 rows held per thread; 0 = none
+static int gn_cluster_split(int nslab, int HW, int noct) {
+    const int rows_par = 512 / noct;
+    for (int S = 2; S <= 8 && nslab * S <= kGnClusterMaxWgs; S *= 2) {
+        const int rpc = (HW + S - 1) / S;
+        if ((rpc + rows_par - 1) / rows_par <= 16) return S;
+    }
+    return 0;
+}
+
 static int64_t gn_ws_stats_floats(int B) { return (int64_t)B * kGnMaxChunks * 256 * 2; }
-constexpr int kGnClusterFloats = kGnClusterMaxWgs * 8 + kGnClusterMaxWgs * 2;   // head of the workspace
+constexpr int kGnClusterFloats = kGnClusterMaxWgs * 8 + kGnClusterMaxWgs * 2 + 8;   // head of the workspace (+ the timeout counter)
 
 extern "C" int64_t pcdm_groupnorm_ws_floats(int B, int C) {
     (void)C;
@@ -625,6 +686,19 @@ extern "C" int64_t pcdm_groupnorm_ws_floats(int B, int C) {
     // statistics, a launch of another shape left float bit patterns in them, the poll fell through at once and the partners' sums were
     // read before they were written (2-4 % run-to-run differences in the full-size UNet forward).
     return kGnClusterFloats + gn_ws_stats_floats(B);
+}
+
+extern "C" int pcdm_groupnorm_cluster_timeouts(const float* ws, unsigned* count_out, pcdm_stream_t s) {
+    if (!ws || !count_out) return -1;
+    (void)s;
+    const unsigned* src = (const unsigned*)(ws + kGnClusterMaxWgs * 8) + kGnClusterMaxWgs * 2;
+#ifdef PCDM_EMU
+    *count_out = *src;
+    return 0;
+#else
+    // (a synchronous 4-byte read: diagnostics / tests only)
+    return hipMemcpy(count_out, src, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1000;
+#endif
 }
 
 extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
@@ -645,7 +719,10 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
             return (int64_t)(e ? atoi(e) : 352) * 1024;
         }();
         const bool few_slabs = (groups / gpb) * B <= 128 && HW >= 1024;   // <= 128 long workgroups: the cluster kernel below fills the chip
-        if (gpb <= 4 && groups % gpb == 0 && noct <= 64 && (int64_t)HW * noct * 16 <= max_slab && !(few_slabs && gn_cluster_enabled())) {
+        // (only when the cluster kernel can actually take the shape: otherwise the single-pass path stays the better one)
+        const bool to_cluster = few_slabs && gpb <= 4 && groups % gpb == 0 && noct <= 64 && gn_cluster_enabled() &&
+                                gn_cluster_split((groups / gpb) * B, HW, noct) > 0;
+        if (gpb <= 4 && groups % gpb == 0 && noct <= 64 && (int64_t)HW * noct * 16 <= max_slab && !to_cluster) {
             // rows per thread at 256 / 512 / 1024 threads, at most 8 (all loads of the slab in flight at once, <= 128 KiB)
             auto need = [&](int th) { return (HW + th / noct - 1) / (th / noct); };
             const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
@@ -672,10 +749,9 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
         if (gn_cluster_enabled() && gpb <= 4 && groups % gpb == 0 && noct <= 64) {
             const int nslab = (groups / gpb) * B;
             const int rows_par = 512 / noct;   // 512 threads: 256 registers per lane, no spills with 16 rows held per thread
-            for (int S = 2; S <= 8 && nslab * S <= kGnClusterMaxWgs; S *= 2) {
+            if (const int S = gn_cluster_split(nslab, HW, noct)) {
                 const int rpc = (HW + S - 1) / S;
                 const int need = (rpc + rows_par - 1) / rows_par;
-                if (need > 16) continue;
                 float* cws = ws;   // cluster area at the head of the workspace: [kGnClusterMaxWgs][8] partials, then the counters
                 const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
                 const double inv_n = 1.0 / ((double)HW * gs);

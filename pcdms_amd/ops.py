@@ -54,6 +54,14 @@ def groupnorm_ws(B: int, C: int, device) -> torch.Tensor:
     return torch.zeros(n, dtype=torch.float32, device=device)   # arrival counters must start at zero
 
 
+def groupnorm_cluster_timeouts(ws: torch.Tensor) -> int:
+    """How many workgroups of the in-launch-exchange GroupNorm path gave up waiting for their partners (and computed alone) since the
+    workspace was allocated; 0 unless something else held CUs during a launch.  Synchronous (diagnostics / tests)."""
+    n = C.c_uint(0)
+    _chk(_lib.lib().pcdm_groupnorm_cluster_timeouts(_ptr(ws), C.byref(n), None), "pcdm_groupnorm_cluster_timeouts")
+    return int(n.value)
+
+
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
               gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
     """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16."""
@@ -221,8 +229,10 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         e0.record()
         _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
         e1.record()
-        # algorithmic FLOPs stay the un-hoisted 2*M*N*K also when zero_rows skips part of the contraction
-        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split)))
+        # algorithmic FLOPs stay the un-hoisted 2*M*N*K also when zero_rows skips part of the contraction; the sixth
+        # field is what the launch executes
+        LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split),
+                           2.0 * (M - zero_rows) * pw.alg_nk))
         return out
     _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
     return out

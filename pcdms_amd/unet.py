@@ -436,7 +436,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 cond.kv[p] = (kbuf, vtbuf)
         return cond
 
-    def _conditioning_for(self, B, h, w, ehs, class_labels, pose) -> "Conditioning":
+    def _conditioning_for(self, B, h, w, ehs, class_labels, pose, zero_ctx_batches: Optional[int] = None) -> "Conditioning":
         """Bare ``forward`` callers (the reference pipeline's own loop): reuse the last conditioning
         iff the caller passed the SAME tensor objects, unmodified (torch's in-place version counter), and nobody has
         overwritten the buffers since.  The entry keeps the three tensors alive, so a fresh tensor can never sit at a
@@ -446,9 +446,10 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         if hit is not None:
             hsrcs, vers, shape, cond = hit
             if shape == (B, h, w) and cond.gen == self._cond_gen and all(a is b for a, b in zip(srcs, hsrcs)) and \
-                    vers == tuple(None if t is None else t._version for t in srcs):
+                    vers == tuple(None if t is None else t._version for t in srcs) and \
+                    (zero_ctx_batches is None or min(zero_ctx_batches, max(B - 1, 0)) == cond.n0):
                 return cond
-        cond = self.prepare_conditioning(B, h, w, ehs, class_labels, pose)
+        cond = self.prepare_conditioning(B, h, w, ehs, class_labels, pose, zero_ctx_batches=zero_ctx_batches)
         self._cache["cond"] = (srcs, tuple(None if t is None else t._version for t in srcs), (B, h, w), cond)
         return cond
 
@@ -466,7 +467,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 mid_block_additional_residual: Optional[torch.Tensor] = None,
                 encoder_attention_mask: Optional[torch.Tensor] = None, my_pose_cond: Optional[torch.Tensor] = None,
                 return_dict: bool = True, _step_dev: Optional[torch.Tensor] = None,
-                _cond: Optional["Conditioning"] = None):
+                _cond: Optional["Conditioning"] = None, zero_ctx_batches: Optional[int] = None):
+        """``zero_ctx_batches`` (extension; bare callers only): how many LEADING batch entries of ``encoder_hidden_states`` are
+        all-zero (the CFG unconditional half): their cross-attention is skipped.  ``None`` = find out with one device reduction and a
+        host sync per conditioning-cache miss -- except while the stream is being captured into a hipGraph, where no sync is possible
+        and 0 is assumed (every row computed in full; same result).  Callers that rebuild ``encoder_hidden_states`` every step
+        should pass the number (or 0) to avoid the sync; see INTEGRATION.md §1."""
         for name, v in (("timestep_cond", timestep_cond), ("attention_mask", attention_mask),
                         ("added_cond_kwargs", added_cond_kwargs),
                         ("down_block_additional_residuals", down_block_additional_residuals),
@@ -491,7 +497,10 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             raise RuntimeError(f"sample on {sample.device}, model on {self._device}")
         x_in = ops.nchw_to_nhwc_bf16(sample, self._buf("x_in", (B, h, w, self._w["conv_in"].cin)),
                                      cpad=self._w["conv_in"].cin)
-        cond = _cond if _cond is not None else self._conditioning_for(B, h, w, encoder_hidden_states, class_labels, my_pose_cond)
+        if zero_ctx_batches is None and sample.is_cuda and torch.cuda.is_current_stream_capturing():
+            zero_ctx_batches = 0
+        cond = _cond if _cond is not None else self._conditioning_for(B, h, w, encoder_hidden_states, class_labels, my_pose_cond,
+                                                                     zero_ctx_batches)
         eps = self._forward_nhwc(x_in, B, h, w, timestep, cond, _step_dev)
         # a fresh tensor at the public boundary (nn.Module semantics: two calls never alias); the fused pipeline path uses
         # _forward_nhwc directly and reads the reused buffer in place

@@ -12,7 +12,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $REPO/tools/profile_step.py > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $REPO/tools/profile_step.py > /dev/null 2>&1
 cd $REPO
-python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/kernel_traffic.json 2> $OUT/kernel_traffic.err
+python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/gemm_traffic.json > $OUT/kernel_traffic.json 2> $OUT/kernel_traffic.err
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 python tools/kernel_trace_summary.py $OUT/stats > $OUT/kernel_step_summary.txt 2> $OUT/kernel_step_summary.err
