@@ -355,10 +355,11 @@ def cpu_baseline(sd, cfg, inp, N, ddim_steps):
     sch.set_timesteps(ddim_steps)
     lat = inp["latents"].clone()
     threads_before = torch.get_num_threads()
-    # thread counts to time: the PHYSICAL cores of one socket, and of the whole box.  torch's default is the number of
+    # thread counts to time: the PHYSICAL cores of one socket, and half of them.  torch's default is the number of
     # LOGICAL CPUs (round 2 timed 128 threads on a 2 x 32-core box: hyper-threads and the second socket's memory made the fp32 GEMMs
     # ~4x slower than 8 threads on 8 cores).  `value` / `cores` are the better of the two.
-    counts = sorted({topo["cores_per_socket"], topo["physical_cores"]})
+    # (measured on the 2 x 64-core driver box: 64 threads 27.5 s per step, 128 threads 41.8 s -- more threads are SLOWER there)
+    counts = sorted({max(1, topo["cores_per_socket"] // 2), topo["cores_per_socket"]})
 
     def one_step(nthreads):
         torch.set_num_threads(nthreads)

@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libpcdm.so"
-SOURCES = ["norm.hip", "gemm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip"]
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]   # MFMA accumulators in arch VGPRs (no v_accvgpr moves)
 NO_VGPR_FORM: set = set()
 EXTRA_DEPS: dict = {}
@@ -40,7 +40,7 @@ def _stale(out: Path, deps) -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     LIBDIR.mkdir(exist_ok=True)
-    headers = [CSRC / "pcdm_device.h", ROOT.parent / "include" / "pcdm.h"]
+    headers = [CSRC / "pcdm_device.h", CSRC / "gemm_args.h", ROOT.parent / "include" / "pcdm.h"]
     objs, jobs = [], []
     for src in SOURCES:
         s = CSRC / src

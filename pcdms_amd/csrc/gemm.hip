@@ -22,55 +22,17 @@
 //    walks all N-tiles of an A tile back to back (cdna_hip_programming.md T1, bijective form).
 //  * What bounds it: with real operands the MFMA + LDS loop without any global loads sustains 1.1-1.5 PF/s (power), and
 //    a CU fills its LDS from L2 at 23-37 B per cycle; the 192x320 tile (120 FLOP per staged byte) sits at both limits at once.
-#include "pcdm_device.h"
-#include "../../include/pcdm.h"
+#include "gemm_args.h"
 
 #include <type_traits>
 
-namespace pcdm_gemm_detail {
-struct GemmArgs {
-    const u16* a;
-    const u16* a2;
-    int64_t lda, lda2;
-    int c1;
-    int B, Hi, Wi, Ho, Wo, stride, upsample, cin;
-    int pad;   // conv: 1 = symmetric zero padding 1 (default); 0 = bottom/right only (VAE encoder Downsample2D)
-    const u16* w;
-    int64_t ldw;   // row stride of W in elements (>= K)
-    int M, N, K, Npad;
-    const float* bias;
-    const float* rowvec;
-    int ldrv;
-    int rows_per_batch;
-    const u16* residual;
-    int64_t ldr;
-    int res_mod;
-    int epilogue;
-    int vt_col0;
-    void* out;
-    int64_t ldo;
-    u16* out2;
-    int64_t ldo2;
-    int tiles_m, tiles_n;
-    int split_k;   // > 1: K range split over split_k workgroups per tile, fp32 partials to ws, reduced by splitk_reduce_kernel
-    float* ws;
-    int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
-    int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
-    int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
-                // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)
-};
-}  // namespace pcdm_gemm_detail
+
 
 namespace {
 using pcdm_gemm_detail::GemmArgs;
+using pcdm_gemm_detail::apply_act;
+using pcdm_gemm_detail::gate_act;
 constexpr int BK = 64;
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;
-}
-
-// gated-linear-unit epilogue: GEGLU (diffusers FeedForward, act == 0) or SwiGLU (DINOv2 SwiGLUFFN, act == PCDM_ACT_SILU)
-__device__ __forceinline__ float gate_act(float g, int act) { return act == PCDM_ACT_SILU ? silu_f(g) : gelu_erf_f(g); }
 
 // 32 bytes of zeros: the source of every epilogue operand that is absent (no bias / row vector / residual) or out of range, so
 // that the epilogue's loads are UNCONDITIONAL: a load inside `if (p.bias)` costs a branch plus an s_waitcnt vmcnt(0) of its own
@@ -963,6 +925,9 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.zero_rows = p->zero_rows;
     if (a.zero_rows < 0 || a.zero_rows > p->M || (a.zero_rows && p->conv)) return -1;
     if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act == PCDM_ACT_GELU && p->epilogue == PCDM_EPI_GEGLU)) return -1;
+    a.ln_gamma = p->ln_gamma;
+    a.ln_beta = p->ln_beta;
+    a.ln_eps = p->ln_eps;
     a.split_k = p->split_k > 1 ? p->split_k : 1;
     a.ws = p->ws;
     if (a.split_k > 1) {
@@ -980,6 +945,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (p->epilogue == PCDM_EPI_SPLIT_VT && (!p->out2 || p->vt_col0 % 4)) return -1;
     hipStream_t st = (hipStream_t)s;
     int tile = p->tile & 0xff;
+    if (tile >= pcdm_gemm_detail::kRowGemmTile0) return p->conv ? -1 : pcdm_gemm_detail::launch_rowgemm(tile, a, st);
+    if (a.ln_gamma) return -1;   // LayerNorm-on-load exists in the A-in-registers kernel only
     const bool n128 = p->Npad % 128 == 0;
     const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11 || tile == 18;
     if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile (19+: launch_gemm checks)

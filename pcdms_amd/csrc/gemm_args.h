@@ -1,0 +1,54 @@
+// Kernel-argument block shared by the GEMM kernels (gemm.hip: tiled GEMM / implicit-GEMM conv; rowgemm.hip: the A-in-registers
+// thin-K kernel) and the few epilogue helpers both use.
+#pragma once
+#include "pcdm_device.h"
+#include "../../include/pcdm.h"
+
+namespace pcdm_gemm_detail {
+struct GemmArgs {
+    const u16* a;
+    const u16* a2;
+    int64_t lda, lda2;
+    int c1;
+    int B, Hi, Wi, Ho, Wo, stride, upsample, cin;
+    int pad;   // conv: 1 = symmetric zero padding 1 (default); 0 = bottom/right only (VAE encoder Downsample2D)
+    const u16* w;
+    int64_t ldw;   // row stride of W in elements (>= K)
+    int M, N, K, Npad;
+    const float* bias;
+    const float* rowvec;
+    int ldrv;
+    int rows_per_batch;
+    const u16* residual;
+    int64_t ldr;
+    int res_mod;
+    int epilogue;
+    int vt_col0;
+    void* out;
+    int64_t ldo;
+    u16* out2;
+    int64_t ldo2;
+    int tiles_m, tiles_n;
+    int split_k;   // > 1: K range split over split_k workgroups per tile, fp32 partials to ws, reduced by splitk_reduce_kernel
+    float* ws;
+    int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
+    int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
+    const float* ln_gamma;   // rowgemm only: LayerNorm (over K, eps ln_eps) applied to every A row while it is loaded
+    const float* ln_beta;
+    float ln_eps;
+    int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
+                // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)
+};
+}  // namespace pcdm_gemm_detail
+
+namespace pcdm_gemm_detail {
+__device__ __forceinline__ float apply_act(float v, int act) {
+    return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;
+}
+// gated-linear-unit epilogue: GEGLU (diffusers FeedForward, act == 0) or SwiGLU (DINOv2 SwiGLUFFN, act == PCDM_ACT_SILU)
+__device__ __forceinline__ float gate_act(float g, int act) { return act == PCDM_ACT_SILU ? silu_f(g) : gelu_erf_f(g); }
+
+// tile ids >= kRowGemmTile0 of pcdm_gemm_params.tile: rowgemm.hip (returns -1 when the problem / epilogue is not one it takes)
+constexpr int kRowGemmTile0 = 31;
+int launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st);
+}  // namespace pcdm_gemm_detail

@@ -560,10 +560,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
             t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)))
             # self-attention
-            l1 = ops.layernorm(t0, a["ln1"][0], a["ln1"][1], 1e-5, self._buf("ln", (M, c)))
+            # LayerNorm -> projection pairs go through ops.gemm(ln=...): at K = 320 (level 0) the A-in-registers kernel normalises the
+            # rows while loading them (no LayerNorm launch, no normalised tensor in memory); elsewhere LayerNorm runs first into "ln"
             qk = self._buf("qk", (M, 2 * c))
             vt = self._buf("vt", (B, c, (HW_ + 7) // 8 * 8), zero=True)
-            ops.gemm(l1, a["qkv"], qk, rows_per_batch=HW_, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * c)
+            ops.gemm(t0, a["qkv"], qk, rows_per_batch=HW_, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * c,
+                     ln=(a["ln1"][0], a["ln1"][1], 1e-5), ln_buf=self._buf("ln", (M, c)))
             if self._attn_fp8:
                 HW16 = (HW_ + 15) // 16 * 16
                 k8 = ops.quantize_fp8(qk[:, c:], self._buf("k8", (M, c), ops.FP8))
@@ -576,15 +578,15 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             # attn2(x) == to_out.0.bias exactly: their rows skip LN2 / to_q / attention and enter
             # the to_out GEMM as zero A rows (no main loop for tiles that lie entirely inside them)
             r0 = nzero * HW_
-            l2 = ops.layernorm(t1[r0:], a["ln2"][0], a["ln2"][1], 1e-5, self._buf("ln", (M, c))[r0:])
-            q2 = ops.gemm(l2, a["q2"], self._buf("q2", (M, c))[r0:])
+            q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
+                          ln_buf=self._buf("ln", (M, c))[r0:])
             k2, vt2 = kv[p]
             at2 = self._buf("at", (M, c))
             (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
             t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0)
             # GEGLU feed-forward
-            l3 = ops.layernorm(t2, a["ln3"][0], a["ln3"][1], 1e-5, self._buf("ln", (M, c)))
-            ff = ops.gemm(l3, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU)
+            ff = ops.gemm(t2, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU, ln=(a["ln3"][0], a["ln3"][1], 1e-5),
+                          ln_buf=self._buf("ln", (M, c)))
             t3 = ops.gemm(ff, a["ff2"], self._buf("t1", (M, c)), residual=t2, res_mod=M)
             return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M)
 

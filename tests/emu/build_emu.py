@@ -15,7 +15,7 @@ ROOT = HERE.parent.parent
 CSRC = ROOT / "pcdms_amd" / "csrc"
 OUT = HERE / "_build"
 LIB = OUT / "libpcdm_emu.so"
-SOURCES = ["norm.hip", "gemm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip"]
 
 
 def _cxx() -> str:
@@ -27,7 +27,7 @@ def _cxx() -> str:
 
 def build(force: bool = False) -> Path:
     OUT.mkdir(exist_ok=True)
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "pcdm_device.h", ROOT / "include" / "pcdm.h", HERE / "hip_emu.h",
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "pcdm_device.h", CSRC / "gemm_args.h", ROOT / "include" / "pcdm.h", HERE / "hip_emu.h",
                                           HERE / "hip_emu.cpp"]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB

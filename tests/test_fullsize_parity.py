@@ -42,7 +42,8 @@ FWD_TOL = 2.5e-2      # one forward, rel-L2 of the guided eps: the suite's forwa
 FP8_FWD_TOL = 6e-2    # one forward with fp8 (e4m3) attention operands -- configs[4]'s own, looser tolerance
 TRAJ_TOL = 1.5e-3     # latents along / at the end of the 50-step trajectory (measured 0.7e-3 .. 0.8e-3: the DDIM update is dominated by
                       # its deterministic rescale of the latents, which both sides compute in fp32)
-EPS_PART_TOL = 2.5e-2  # the eps-driven part of the same latents, lat_i - c_x(i) lat_0: the accumulated UNet contribution (one forward: FWD_TOL)
+EPS_PART_TOL = 1.2e-2  # the eps-driven part of the same latents, lat_i - c_x(i) lat_0: the accumulated UNet contribution (measured 0.52e-2 .. 0.67e-2;
+                       # a single forward is at 0.95e-2 .. 1.67e-2: the per-step errors partly average out along the trajectory)
 FP8_VS_BF16_TOL = 2e-2  # guided eps with fp8 attention vs the bf16-attention path, same weights and inputs (UNet batch 32)
 PIX_TOL = 1.0         # mean absolute difference in uint8 levels over a canvas (measured 0.34; bf16 VAE alone 0.34)
 PIX_MEAN_TOL = 0.25   # |mean(canvas) - mean(oracle canvas)| in uint8 levels (measured <= 0.022)

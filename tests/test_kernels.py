@@ -627,3 +627,86 @@ def test_gemm_full_row_tiles_and_zero_rows(backend):
         ops.gemm(xh, pwc, out, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tile=tile)
         backend.sync()
         close(out.view(B, H, W, Cout), refc)
+
+
+def test_rowgemm_thin_k(backend):
+    """rowgemm.hip (tiles 31..34): the K = 320 GEMM with the activation rows stationary in registers and the weights streamed through one
+    LDS ring across all N tiles -- bias + residual store (with an M tail and ``zero_rows``), GEGLU, the q|k / V^T split epilogue, and
+    LayerNorm applied to the rows while they are loaded (vs LayerNorm -> GEMM in two steps, fp32 reference)."""
+    dev = backend.device
+    K = 320
+    g = torch.Generator().manual_seed(90)
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+
+    def ln_ref(x):
+        return F.layer_norm(x.float(), (K,), gamma, beta, 1e-5).to(BF16).float()   # the fused path rounds LN(x) to bf16, like pcdm_layernorm
+
+    # ---- plain store: bias + residual, M tail, several N-tile counts
+    for (M, N, tiles) in ([(200, 128, (31, 32, 33)), (100, 320, (32,))] if backend.is_emu else
+                          [(45056, 320, (31, 32, 33, 34)), (22528 + 40, 320, (32, 33)), (45056, 960, (32,)), (1000, 1280, (31, 32, 33, 34))]):
+        a = rnd(M, K, seed=91)
+        w = rnd(N, K, seed=92, scale=1 / math.sqrt(K))
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(93))
+        res = rnd(M, N, seed=94)
+        pw = ops.pack_linear(w.float(), bias, dev)
+        ref = a.float() @ w.float().t() + bias + res.float()
+        ref_ln = ln_ref(a) @ w.float().t() + bias
+        for tile in tiles:
+            if pw.Npad % ops.TILE_SHAPES[tile][1]:
+                continue
+            out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(a.to(dev), pw, out, residual=res.to(dev), res_mod=M, tile=tile)
+            backend.sync()
+            close(out, ref)
+            out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(a.to(dev), pw, out, tile=tile, ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, K, dtype=BF16, device=dev))
+            backend.sync()
+            close(out, ref_ln)
+        # zero_rows: garbage in the declared-zero rows must not be read (one value inside a workgroup's rows, one covering whole workgroups)
+        for z in ((40, 192) if backend.is_emu else (777, 192 * 100)):
+            ag = a.clone()
+            ag[:z] = float("nan")
+            az = a.float().clone()
+            az[:z] = 0
+            out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(ag.to(dev), pw, out, residual=res.to(dev), res_mod=M, tile=tiles[-1] if not pw.Npad % ops.TILE_SHAPES[tiles[-1]][1] else 32,
+                     zero_rows=min(z, M))
+            backend.sync()
+            close(out, az @ w.float().t() + bias + res.float())
+    # ---- GEGLU (+ LayerNorm): tiles whose waves own 64 columns
+    M, D = (120, 128) if backend.is_emu else (45056, 1280)
+    a = rnd(M, K, seed=95)
+    w = rnd(2 * D, K, seed=96, scale=1 / math.sqrt(K))
+    bias = torch.randn(2 * D, generator=torch.Generator().manual_seed(97)) * 0.5
+    pw = ops.pack_geglu(w.float(), bias, dev)
+    for use_ln in (False, True):
+        pr = (ln_ref(a) if use_ln else a.float()) @ w.float().t() + bias
+        h, gt = pr.chunk(2, -1)
+        for tile in (31, 34):
+            out = torch.full((M, D), float("nan"), dtype=BF16, device=dev)
+            kw = dict(ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, K, dtype=BF16, device=dev)) if use_ln else {}
+            ops.gemm(a.to(dev), pw, out, epilogue=ops.EPI_GEGLU, tile=tile, **kw)
+            backend.sync()
+            close(out, h * F.gelu(gt))
+    # ---- q | k | v^T (+ LayerNorm): N = 3C, tokens per batch entry a multiple of 16
+    Bq, T, Cc = (2, 48, 64) if backend.is_emu else (8, 5632, 320)
+    x = rnd(Bq * T, K, seed=98)
+    wq = rnd(3 * Cc, K, seed=99, scale=1 / math.sqrt(K))
+    pwq = ops.pack_linear(wq.float(), None, dev)
+    for use_ln in (False, True):
+        pr = (ln_ref(x) if use_ln else x.float()) @ wq.float().t()
+        for tile in (31, 32, 33):
+            if pwq.Npad % ops.TILE_SHAPES[tile][1] or (2 * Cc) % (ops.TILE_SHAPES[tile][1] // (2 if tile in (31, 32) else 4)):
+                continue
+            qk = torch.full((Bq * T, 2 * Cc), float("nan"), dtype=BF16, device=dev)
+            vt = torch.zeros(Bq, Cc, T + 8, dtype=BF16, device=dev)
+            kw = dict(ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(Bq * T, K, dtype=BF16, device=dev)) if use_ln else {}
+            ops.gemm(x.to(dev), pwq, qk, rows_per_batch=T, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * Cc, tile=tile, **kw)
+            backend.sync()
+            close(qk, pr[:, : 2 * Cc])
+            close(vt[:, :, :T], pr[:, 2 * Cc:].view(Bq, T, Cc).permute(0, 2, 1))
+            assert (vt[:, :, T:] == 0).all(), tile
+    # the kernel is K = 320 only and says so
+    pw64 = ops.pack_linear(rnd(64, 64, seed=1).float(), None, dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(rnd(32, 64, seed=2).to(dev), pw64, torch.empty(32, 64, dtype=BF16, device=dev), tile=31)
