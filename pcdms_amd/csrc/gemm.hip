@@ -72,9 +72,12 @@ __device__ __forceinline__ void lean_res_load(const GemmArgs& p, int lane, int m
     for (int it = 0; it < G::NIT; ++it) rv[it] = buf_load16(rs_r, (G::TAIL && it * G::RPI + rl >= 32) ? kOOB : vr0 + it * sr);
 }
 
-template <int WCOLS, int EPW, bool HAS_RV>
+// RV: 0 = no row vector, 1 = row vector from the wave's LDS slice (rows b_lo and b_lo + 1 of it, staged before the first store), 2 = from
+// global memory per store instruction (wave tiles that span more than two batch entries: the 8x11 level)
+template <int WCOLS, int EPW, int RV>
 __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, f32x4 b0, f32x4 b1,
-                                          BufRsrc rs_o, BufRsrc rs_v, const u32x4 (&rv)[4]) {
+                                          BufRsrc rs_o, BufRsrc rs_v, const u32x4 (&rv)[4], const float* rvec_w, int rv_pitch,
+                                          int rv_col0, int rv_split_row) {
     typedef PassGeom<WCOLS> G;
     constexpr int LPR = G::LPR, RPI = G::RPI, NIT = G::NIT;
     constexpr bool TAIL = G::TAIL;
@@ -84,13 +87,26 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
     const bool lane_ok = rl < RPI && n < p.N;
     const uint32_t vo0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldo + n) * 2) : kOOB;
     const uint32_t so = (uint32_t)(RPI * (int)p.ldo * 2);
+    f32x4 t0[2], t1[2];
+    if constexpr (RV == 1) {   // the two candidate rows of the time-embedding projection, from LDS: no vector-memory load behind a store
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            t0[h] = *(const f32x4*)(rvec_w + h * rv_pitch + rv_col0 + c8);
+            t1[h] = *(const f32x4*)(rvec_w + h * rv_pitch + rv_col0 + c8 + 4);
+        }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int r = it * RPI + rl;
         const int rr = (TAIL && r >= 32) ? 0 : r;
         const f32x4 v0 = *(const f32x4*)(ep + rr * EPW + c8), v1 = *(const f32x4*)(ep + rr * EPW + c8 + 4);
         f32x4 a0 = v0 + b0, a1 = v1 + b1;
-        if constexpr (HAS_RV) {   // rows of one instruction span at most two batch entries (rows_per_batch >= 32 on this path)
+        if constexpr (RV == 1) {
+            const bool hi = mrow0 + r >= rv_split_row;   // first row of batch entry b_lo + 1
+            a0 += hi ? t0[1] : t0[0];
+            a1 += hi ? t1[1] : t1[0];
+        }
+        if constexpr (RV == 2) {   // rows of one instruction span at most two batch entries (rows_per_batch >= 32 on this path)
             const int mb = mrow0 + it * RPI;                        // wave-uniform
             const int b_lo = mb / p.rows_per_batch;
             const int bidx = b_lo + ((mb + rl) >= (b_lo + 1) * p.rows_per_batch ? 1 : 0);
@@ -116,7 +132,8 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
 // channel and 8 consecutive tokens -- and stored as 16 bytes along the token axis of out2[b, channel, token]: 64 contiguous bytes
 // per channel per pass instead of 2-byte scalar stores.  The 32 rows of a pass lie inside one batch entry (rows_per_batch % 32 == 0).
 template <int WCOLS, int EPW>
-__device__ __forceinline__ void vt_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, BufRsrc rs_vt) {
+__device__ __forceinline__ void vt_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, BufRsrc rs_vt,
+                                        const float* bias_c /* the wave's LDS bias slice at column ncol0 */) {
     constexpr uint32_t kOOB = 0x80000000u;
     const int b = mrow0 / p.rows_per_batch, tok0 = mrow0 - b * p.rows_per_batch;   // wave-uniform
     const int cl = lane & 15, tg = lane >> 4;
@@ -125,7 +142,7 @@ __device__ __forceinline__ void vt_pass(const GemmArgs& p, const float* ep, int 
     for (int ii = 0; ii < WCOLS / 16; ++ii) {
         const int c = ii * 16 + cl, n = ncol0 + c;
         const bool ok = n < p.N;
-        const float bias = *((p.bias && ok) ? p.bias + n : (const float*)g_zero32);
+        const float bias = bias_c[c];
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = ep[(8 * tg + i) * EPW + c] + bias;
@@ -586,21 +603,63 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         const BufRsrc rs_vt = make_buf_rsrc(v_tile ? (const void*)p.out2 : (const void*)p.out,
                                             v_tile ? (uint32_t)((int64_t)(p.M / p.rows_per_batch) * (p.N - p.vt_col0) * p.ldo2 * 2) : 0u);
         float* ep = (float*)smem + wave * (32 * EPW);      // wave-private 32 x (CG*F) tile
+        // Everything the epilogue READS from global memory is fetched before its first store: a wave's vector-memory operations leave
+        // its vmcnt counter in issue order, loads and stores alike, so a load issued behind a store (a bias quad per column group, a
+        // row-vector quad per store instruction, a residual row two passes ahead -- the round-2 schedule) is handed over only after
+        // that store has been acknowledged by the L2 / HBM: one exposed write round trip per pass (tools/gemm_anatomy.py: 22 k cycles
+        // of epilogue with a residual, 10.5 k without).  Bias and the two time-embedding rows the wave tile can touch go to a
+        // wave-private LDS slice, the residual rows of all passes to registers.
+        constexpr int WNP = (WN + 3) / 4 * 4;
+        float* bias_w = (float*)smem + NW * (32 * EPW) + wave * (3 * WNP);
+        float* rvec_w = bias_w + WNP;
+        const int wrow0 = m0 + wm * WM, wcol0 = n0 + wn * WN;
+        const int rv_blo = wrow0 / p.rows_per_batch;
+        const bool rv_lds = has_rv && (wrow0 + WM - 1) / p.rows_per_batch <= rv_blo + 1;
+        const int rv_split_row = (rv_blo + 1) * p.rows_per_batch;
+        if (lane * 4 < WN) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(bias_w + lane * 4) = p.bias ? *(const f32x4*)(p.bias + wcol0 + lane * 4) : z4;
+            if (rv_lds) {
+                const int c = wcol0 + lane * 4;
+                const int nb = (p.M - 1) / p.rows_per_batch;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int b = rv_blo + h < nb ? rv_blo + h : nb;
+                    f32x4 v = z4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.N) v[e] = p.rowvec[(int64_t)b * p.ldrv + c + e];
+                    *(f32x4*)(rvec_w + h * WNP + lane * 4) = v;
+                }
+            }
+        }
+        PCDM_WAVE_SYNC();
         constexpr int NCG = (FN + CG - 1) / CG, NJB = WM / 32;
         // pass q = (column group q / NJB, row block q % NJB); GEGLU needs WN == 64, i.e. a single column group
-        u32x4 rv[NCG * NJB][4];                            // residual rows, loaded two passes ahead (static indices: registers)
+        // The pass loop exists twice: with and without a residual operand.  The residual rows of ALL passes sit in registers from before
+        // the first store (96 VGPRs for a 96x80 wave tile); the instance without a residual does not carry them (a single instance
+        // with a run-time flag spilled into scratch, whose reloads are vector-memory loads behind stores again).
+        auto run_passes = [&](auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        u32x4 rv[RES ? NCG * NJB : 1][4];                  // residual rows of every pass (static indices: registers)
         auto pass_cols = [&](int q) { const int i0 = (q / NJB) * CG; return geglu ? 32 : ((FN - i0) < CG ? (FN - i0) : CG) * F; };
         auto pass_ncol0 = [&](int q) { return geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN + (q / NJB) * CG * F; };
         auto issue_res = [&](int q) {
+            if constexpr (!RES) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) rv[0][it] = u32x4{0, 0, 0, 0};
+                return;
+            }
             const int mrow0 = m0 + wm * WM + (q % NJB) * 32, wc = pass_cols(q), nc = pass_ncol0(q);
             if (wc == 64) lean_res_load<64>(p, lane, mrow0, nc, rs_r, rv[q]);
             else if (wc == 32) lean_res_load<32>(p, lane, mrow0, nc, rs_r, rv[q]);
             else if (wc == 16) lean_res_load<16>(p, lane, mrow0, nc, rs_r, rv[q]);
             else lean_res_load<48>(p, lane, mrow0, nc, rs_r, rv[q]);
         };
-        issue_res(0);
-        if (NCG * NJB > 1) issue_res(1);
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;          // bias of this lane's 8 channels: reloaded once per column group
+        // residual rows of ALL passes -> registers, before the first store (see above)
+#pragma unroll
+        for (int q = 0; q < (RES ? NCG * NJB : 1); ++q) issue_res(q);
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;          // bias of this lane's 8 channels: re-read (LDS) once per column group
 #pragma unroll
         for (int q = 0; q < NCG * NJB; ++q) {
             const int i0 = (q / NJB) * CG, jb = q % NJB;
@@ -608,11 +667,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             const int ncol0 = pass_ncol0(q), wc = pass_cols(q);
             if (jb == 0 && !geglu && !v_tile) {               // (GEGLU applies its biases before the gate, the V^T pass per channel)
                 const int c8_ = (lane % (wc / 8)) * 8;
-                const float* bp = (p.bias && ncol0 + c8_ < p.N) ? p.bias + ncol0 + c8_ : (const float*)g_zero32;
+                const float* bp = bias_w + (ncol0 - wcol0) + c8_;      // (channels >= N hold the packed weights' zero padding)
                 b0 = *(const f32x4*)bp;
                 b1 = *(const f32x4*)(bp + 4);
             }
-            if (q + 2 < NCG * NJB) issue_res(q + 2);
             // 1. quads -> LDS [row = pixel][col = channel]
             if (geglu) {
                 if constexpr (GLU_OK) {
@@ -623,8 +681,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                             for (int rg = 0; rg < NQ; ++rg) {
                                 const int nl = i * F + QS * rg + 4 * half;   // 0..31 within the wave's 32 outputs
-                                const f32x4 bh = *(const f32x4*)(p.bias + n0 + wn * WN + nl);
-                                const f32x4 bg = *(const f32x4*)(p.bias + n0 + wn * WN + nl + 32);
+                                const f32x4 bh = *(const f32x4*)(bias_w + nl);
+                                const f32x4 bg = *(const f32x4*)(bias_w + nl + 32);
                                 const acc_t& ah = acc[i][jb * RB + jj];
                                 const acc_t& ag = acc[i + FN / 2][jb * RB + jj];
                                 f32x4 v;
@@ -652,24 +710,33 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             const int mrow0 = m0 + wm * WM + jb * 32;
             if (v_tile) {
                 if (mrow0 < p.M) {
-                    if (ng * F == 64) vt_pass<64, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
-                    else if (ng * F == 32) vt_pass<32, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
-                    else if (ng * F == 16) vt_pass<16, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
-                    else vt_pass<48, EPW>(p, ep, lane, mrow0, ncol0, rs_vt);
+                    const float* bc = bias_w + (ncol0 - wcol0);
+                    if (ng * F == 64) vt_pass<64, EPW>(p, ep, lane, mrow0, ncol0, rs_vt, bc);
+                    else if (ng * F == 32) vt_pass<32, EPW>(p, ep, lane, mrow0, ncol0, rs_vt, bc);
+                    else if (ng * F == 16) vt_pass<16, EPW>(p, ep, lane, mrow0, ncol0, rs_vt, bc);
+                    else vt_pass<48, EPW>(p, ep, lane, mrow0, ncol0, rs_vt, bc);
                 }
-            } else if (has_rv) {
-                if (wc == 64) lean_pass<64, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
-                else if (wc == 32) lean_pass<32, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
-                else if (wc == 16) lean_pass<16, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
-                else lean_pass<48, EPW, true>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
             } else {
-                if (wc == 64) lean_pass<64, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
-                else if (wc == 32) lean_pass<32, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
-                else if (wc == 16) lean_pass<16, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
-                else lean_pass<48, EPW, false>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[q]);
+                const int rc0 = ncol0 - wcol0;
+#define PCDM_LEAN(W, RVK) lean_pass<W, EPW, RVK>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[RES ? q : 0], rvec_w, WNP, rc0, rv_split_row)
+#define PCDM_LEAN_W(RVK)                 \
+    do {                                 \
+        if (wc == 64) PCDM_LEAN(64, RVK);      \
+        else if (wc == 32) PCDM_LEAN(32, RVK); \
+        else if (wc == 16) PCDM_LEAN(16, RVK); \
+        else PCDM_LEAN(48, RVK);               \
+    } while (0)
+                if (!has_rv) PCDM_LEAN_W(0);
+                else if (rv_lds) PCDM_LEAN_W(1);
+                else PCDM_LEAN_W(2);
+#undef PCDM_LEAN_W
+#undef PCDM_LEAN
             }
             PCDM_WAVE_SYNC();   // this pass's reads precede the next pass's writes
         }
+        };
+        if (has_res) run_passes(std::true_type());
+        else run_passes(std::false_type());
 #ifndef PCDM_EMU
         if ((p.debug & 4) && p.ws) {
             PCDM_STAMP(4);
@@ -800,7 +867,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     // operand ring, or the wave-private fp32 epilogue tiles (32 x (WN + 4) floats per wave) if those need more
     constexpr int smem_ops = STAGES * (BM + BN) * BK * (int)sizeof(u16);
     constexpr int FN_ = BN / WGN / F, CGM_ = 64 / F;
-    constexpr int smem_epi = WGM * WGN * 32 * ((FN_ < CGM_ ? FN_ : CGM_) * F + 4) * (int)sizeof(float);
+    constexpr int WNP_ = (BN / WGN + 3) / 4 * 4;   // + per wave: bias slice and two row-vector rows (3 x WN floats)
+    constexpr int smem_epi = WGM * WGN * (32 * ((FN_ < CGM_ ? FN_ : CGM_) * F + 4) + 3 * WNP_) * (int)sizeof(float);
     constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static bool attr_done = false;
     if (!attr_done) {

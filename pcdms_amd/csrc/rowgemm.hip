@@ -20,13 +20,14 @@
 //    half-batch to_q of the cross-attention (M = 22528);
 //  * epilogues: bias (+ residual) store, GEGLU ([32 h | 32 gate] packed rows, as gemm.hip), q|k store + V^T transposed store -- all
 //    through a wave-private fp32 LDS tile so that every global access is 16 B per lane along the contiguous axis.
-// vmcnt bookkeeping: the ring's counted waits assume that of all vector-memory operations a wave has outstanding, the OLDEST complete
-// first among loads; epilogue stores / residual loads issued between ring operations are not counted, which can only make a wait
-// longer than necessary (never shorter): see wait_stage().
+// vmcnt bookkeeping: vector-memory operations of a wave retire from its counter in issue order, loads and stores alike (gfx9 has one
+// counter for both and hipcc's own waits rely on that order).  The ring's counted waits therefore count, besides the younger ring
+// stages, the epilogue STORES issued since the awaited stage (a fixed number per N tile); loads the epilogue issues (bias, residual)
+// are not counted: an uncounted operation can only make a wait longer than necessary, never shorter.  The first version counted ring
+// stages only: every wait that followed an epilogue then also waited for that epilogue's store acknowledgements (~1.5 us per N tile).
 #include "gemm_args.h"
 
 namespace {
-using pcdm_gemm_detail::gate_act;
 using pcdm_gemm_detail::GemmArgs;
 
 constexpr int kK = 320;            // the contraction length this kernel is built for
@@ -42,8 +43,6 @@ constexpr uint32_t kOOB = 0x80000000u;
 #define RG_KEEP_PACKED(v) asm volatile("" : "+v"(v))
 #endif
 
-__device__ __attribute__((aligned(32))) const unsigned int g_rg_zero32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
 // s_waitcnt vmcnt(n) + lgkmcnt(0), then s_barrier; n is wave-uniform at run time (a scalar switch over immediates)
 __device__ __forceinline__ void wait_stage(int n) {
 #ifdef PCDM_EMU
@@ -55,7 +54,9 @@ __device__ __forceinline__ void wait_stage(int n) {
 #define PCDM_RG_W(N) case N: __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14)); break;
     switch (n) {
         PCDM_RG_W(0) PCDM_RG_W(1) PCDM_RG_W(2) PCDM_RG_W(3) PCDM_RG_W(4) PCDM_RG_W(5) PCDM_RG_W(6) PCDM_RG_W(7) PCDM_RG_W(8)
-        PCDM_RG_W(9) PCDM_RG_W(10) PCDM_RG_W(11) PCDM_RG_W(12) PCDM_RG_W(13) PCDM_RG_W(14)
+        PCDM_RG_W(9) PCDM_RG_W(10) PCDM_RG_W(11) PCDM_RG_W(12) PCDM_RG_W(13) PCDM_RG_W(14) PCDM_RG_W(15) PCDM_RG_W(16)
+        PCDM_RG_W(17) PCDM_RG_W(18) PCDM_RG_W(19) PCDM_RG_W(20) PCDM_RG_W(21) PCDM_RG_W(22) PCDM_RG_W(23) PCDM_RG_W(24) PCDM_RG_W(25)
+        PCDM_RG_W(26) PCDM_RG_W(27) PCDM_RG_W(28) PCDM_RG_W(29) PCDM_RG_W(30) PCDM_RG_W(31) PCDM_RG_W(32)
         default: __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8) | (0 << 14)); break;
     }
 #undef PCDM_RG_W
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     PCDM_DYN_SMEM(smem);
     u16* Ws = (u16*)smem;                                  // [NSTG][BN][64]  (unpadded, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
     float* eps_all = (float*)(Ws + NSTG * BN * 64);        // [NW][16][EPW]
+    float* bias_s = eps_all + NW * 16 * EPW;               // [Npad]: the epilogue reads no global memory (a load behind a store would
+                                                           // wait for that store's acknowledgement: vmcnt retires in issue order)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -101,6 +104,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         b_off[i] = (uint32_t)((int64_t)rl * p.ldw * 2) + (uint32_t)(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
     }
     const int NT = p.Npad / BN;
+    for (int i = t * 4; i < p.Npad; i += NW * 64 * 4) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(bias_s + i) = p.bias ? *(const f32x4*)(p.bias + i) : z4;
+    }
     const bool skip = m0 - wm * (FMW * 16) + BM <= p.zero_rows;   // every row of the workgroup is declared zero: epilogue only
     const int Q = skip ? 0 : NT * kNKT;
     auto issue = [&](int q) {
@@ -208,9 +215,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
                 f32x4 bh[2], bg[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    bh[i] = *(const f32x4*)(p.bias + n0w + i * 16 + 4 * lq);
-                    bg[i] = *(const f32x4*)(p.bias + n0w + 32 + i * 16 + 4 * lq);
+                    bh[i] = *(const f32x4*)(bias_s + n0w + i * 16 + 4 * lq);
+                    bg[i] = *(const f32x4*)(bias_s + n0w + 32 + i * 16 + 4 * lq);
                 }
+                const bool swiglu = p.act == PCDM_ACT_SILU;   // (wave-uniform: one branch per row block, not one per element)
                 const int no = n0w / 2 + (lane & 3) * 8;    // read-back: 4 lanes per row, 16 rows per instruction
                 const int rr = lane >> 2;
 #pragma unroll
@@ -218,8 +226,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         f32x4 v;
+                        if (swiglu) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][e] + bh[i][e]) * gate_act(acc[i + 2][j][e] + bg[i][e], p.act);
+                            for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][e] + bh[i][e]) * silu_f(acc[i + 2][j][e] + bg[i][e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][e] + bh[i][e]) * gelu_erf_f(acc[i + 2][j][e] + bg[i][e]);
+                        }
                         *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = v;
                     }
                     PCDM_WAVE_SYNC();
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 #pragma unroll
                 for (int ii = 0; ii < WNC / 32; ++ii) {
                     const int c = ii * 32 + (lane & 31), th = lane >> 5, n = n0w + c;
-                    const float bias = *((p.bias && n < p.N) ? p.bias + n : (const float*)g_rg_zero32);
+                    const float bias = bias_s[n];
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = ep[(8 * th + e) * EPW + c] + bias;
@@ -263,16 +276,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         const int rl = lane / LPR, c8 = (lane - rl * LPR) * 8;
         const int n = n0w + c8;
         const bool nok = n < p.N;
-        const float* bp = (p.bias && nok) ? p.bias + n : (const float*)g_rg_zero32;
-        const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+        const f32x4 b0 = *(const f32x4*)(bias_s + n), b1 = *(const f32x4*)(bias_s + n + 4);   // (n + 7 < Npad)
+        // every residual row of the tile is requested BEFORE its first store: the counter retires in issue order, so a load issued
+        // behind a store returns only after that store's acknowledgement (a descriptor of size 0 -- no residual -- returns zeros
+        // without touching memory)
+        u32x4 rv[FMW][NIT];
+#pragma unroll
+        for (int j = 0; j < FMW; ++j)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int m = m0 + j * 16 + it * RPI + rl;
+                rv[j][it] = buf_load16(rs_r, nok ? (uint32_t)(((int64_t)m * p.ldr + n) * 2) : kOOB);
+            }
 #pragma unroll
         for (int j = 0; j < FMW; ++j) {
-            u32x4 rv[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {   // (a descriptor of size 0 -- no residual -- returns zeros without touching memory)
-                const int m = m0 + j * 16 + it * RPI + rl;
-                rv[it] = buf_load16(rs_r, nok ? (uint32_t)(((int64_t)m * p.ldr + n) * 2) : kOOB);
-            }
 #pragma unroll
             for (int i = 0; i < FN; ++i) *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = acc[i][j];
             PCDM_WAVE_SYNC();
@@ -282,8 +299,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
                 f32x4 a0 = *(const f32x4*)(ep + r * EPW + c8) + b0, a1 = *(const f32x4*)(ep + r * EPW + c8 + 4) + b1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    a0[e] += __builtin_bit_cast(float, rv[it][e >> 1] << (e & 1 ? 0 : 16) & 0xffff0000u);
-                    a1[e] += __builtin_bit_cast(float, rv[it][2 + (e >> 1)] << (e & 1 ? 0 : 16) & 0xffff0000u);
+                    a0[e] += __builtin_bit_cast(float, rv[j][it][e >> 1] << (e & 1 ? 0 : 16) & 0xffff0000u);
+                    a1[e] += __builtin_bit_cast(float, rv[j][it][2 + (e >> 1)] << (e & 1 ? 0 : 16) & 0xffff0000u);
                 }
                 u32x4 o = {pack2bf(a0[0], a0[1]), pack2bf(a0[2], a0[3]), pack2bf(a1[0], a1[1]), pack2bf(a1[2], a1[3])};
                 const int m = m0 + j * 16 + r;
@@ -293,7 +310,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         }
     };
 
+    // stores every epilogue is guaranteed to issue per wave (masked lanes / rows beyond M still issue the instruction)
+    const int n_ep_stores = geglu ? FMW : FMW * (WNC / 32);
     if (skip) {   // all rows zero: out = bias (+ residual)
+        __syncthreads();   // (bias_s)
         for (int nt = 0; nt < NT; ++nt) epilogue(nt);
         return;
     }
@@ -306,10 +326,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 #pragma unroll
         for (int kt = 0; kt < kNKT; ++kt) {
             const int q = nt * kNKT + kt;
-            // younger ring stages this wave may leave in flight: q + 1 .. min(q + NSTG - 2, Q - 1).  Other vector-memory operations
-            // issued after stage q's (epilogue stores / residual loads) are not counted: the wait is then stricter, never weaker.
+            // operations this wave may leave in flight: the younger ring stages q + 1 .. min(q + NSTG - 2, Q - 1), and the stores of
+            // the epilogues it ran since it issued stage q (in iteration lo = q - NSTG + 1, or in the prologue): an iteration i ends with
+            // an epilogue iff i % kNKT == kNKT - 1, so there are q / kNKT - lo / kNKT of them in [lo, q - 1]
             const int younger = (Q - 1 - q) < (NSTG - 2) ? (Q - 1 - q) : (NSTG - 2);
-            wait_stage(younger * DPW);
+            const int lo = q - (NSTG - 1) > 0 ? q - (NSTG - 1) : 0;
+            wait_stage(younger * DPW + (q / kNKT - lo / kNKT) * n_ep_stores);
             if (q + NSTG - 1 < Q) issue(q + NSTG - 1);
             const u16* ws = Ws + (q % NSTG) * (BN * 64) + (wn * WNC + lrow) * 64;
 #pragma unroll
@@ -335,22 +357,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 template <int WGM, int WGN, int FMW, int BN, int NSTG>
 int launch_rg(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = WGM * FMW * 16, WNC = BN / WGN, NW = WGM * WGN;
-    constexpr int smem = NSTG * BN * 64 * (int)sizeof(u16) + NW * 16 * (WNC + 4) * (int)sizeof(float);
-    if (a.Npad % BN) return -1;
+    constexpr int smem_fixed = NSTG * BN * 64 * (int)sizeof(u16) + NW * 16 * (WNC + 4) * (int)sizeof(float);
+    if (a.Npad % BN || a.Npad > 4096) return -1;
+    const int smem = smem_fixed + a.Npad * (int)sizeof(float);   // + the bias vector
     if (a.epilogue == PCDM_EPI_GEGLU && WNC != 64) return -1;
     if (a.epilogue == PCDM_EPI_SPLIT_VT && (a.vt_col0 % WNC || a.rows_per_batch % 16 || (a.ldo2 & 7) || a.M % 16)) return -1;
     const int grid = (a.M + BM - 1) / BM;
     if (a.ln_gamma) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_fixed + 4096 * (int)sizeof(float));
             attr_done = true;
         }
         PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, true>), dim3(grid), dim3(NW * 64), smem, st, a);
     } else {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_fixed + 4096 * (int)sizeof(float));
             attr_done = true;
         }
         PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, false>), dim3(grid), dim3(NW * 64), smem, st, a);

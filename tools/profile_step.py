@@ -51,7 +51,7 @@ def main():
     torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
     agg = defaultdict(lambda: [0, 0.0, 0.0])
-    for name, flops, a, b, info in log:
+    for name, flops, a, b, info in (e[:5] for e in log):
         k = (name, info)
         agg[k][0] += 1
         agg[k][1] += flops
