@@ -40,7 +40,7 @@ class GemmParams(C.Structure):
         ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32), ("act", C.c_int32),
         ("zero_rows", C.c_int32),
-        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 

@@ -993,8 +993,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.zero_rows = p->zero_rows;
     if (a.zero_rows < 0 || a.zero_rows > p->M || (a.zero_rows && p->conv)) return -1;
     if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act == PCDM_ACT_GELU && p->epilogue == PCDM_EPI_GEGLU)) return -1;
-    a.ln_gamma = p->ln_gamma;
-    a.ln_beta = p->ln_beta;
+    a.ln_wsum = p->ln_wsum;
     a.ln_eps = p->ln_eps;
     a.split_k = p->split_k > 1 ? p->split_k : 1;
     a.ws = p->ws;
@@ -1013,8 +1012,11 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (p->epilogue == PCDM_EPI_SPLIT_VT && (!p->out2 || p->vt_col0 % 4)) return -1;
     hipStream_t st = (hipStream_t)s;
     int tile = p->tile & 0xff;
-    if (tile >= pcdm_gemm_detail::kRowGemmTile0) return p->conv ? -1 : pcdm_gemm_detail::launch_rowgemm(tile, a, st);
-    if (a.ln_gamma) return -1;   // LayerNorm-on-load exists in the A-in-registers kernel only
+    if (tile >= pcdm_gemm_detail::kRowGemmTile0) {
+        if ((a.debug & 4) && p->ws_floats < (int64_t)((p->M + 95) / 96) * 8 * 8 * 2) return -1;   // (stamps: 8 x uint64 per wave)
+        return p->conv ? -1 : pcdm_gemm_detail::launch_rowgemm(tile, a, st);
+    }
+    if (a.ln_wsum) return -1;   // the folded LayerNorm needs the row statistics: the A-in-registers kernel only
     const bool n128 = p->Npad % 128 == 0;
     const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11 || tile == 18;
     if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile (19+: launch_gemm checks)

@@ -33,9 +33,8 @@ struct GemmArgs {
     float* ws;
     int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
-    const float* ln_gamma;   // rowgemm only: LayerNorm (over K, eps ln_eps) applied to every A row while it is loaded
-    const float* ln_beta;
-    float ln_eps;
+    const float* ln_wsum;    // rowgemm only: the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
+    float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
     int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
                 // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)
 };

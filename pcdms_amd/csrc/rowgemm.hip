@@ -10,8 +10,12 @@
 // tensor).  Here:
 //  * one workgroup = 8 waves as WGM x WGN; a wave owns FMW*16 = 48 rows for the whole launch and keeps them as MFMA operand fragments
 //    in registers (16x16x32: 10 k-steps x 3 row blocks x 4 VGPRs = 120); the A rows are read from HBM ONCE, straight into registers;
-//  * LayerNorm (optional, template LNF) is applied to those registers right after the load -- a row is spread over 4 lanes (80
-//    elements each): local sums, two xor-shuffles, exact two-pass variance -- and the normalised rows never exist in memory;
+//  * LayerNorm (optional, template LNF) is FOLDED: gamma goes into the weights and beta into the bias when they are packed
+//    (W' = W diag(gamma), b' = b + W beta), and since LN(x) W'^T = rstd (x W'^T - mean * rowsum(W')), all that is left at run time is
+//    a per-row mean / rstd -- taken from the registers right after the load (a row is spread over 4 lanes: local sums, two
+//    xor-shuffles, exact two-pass variance) -- and one fused multiply-add per accumulator in the epilogue: out = rstd (acc - mean
+//    wsum[n]) + b'[n].  The normalised rows never exist, not even in registers (the first version normalised the fragments in place:
+//    ~2000 VALU instructions per wave in the prologue, 15 k cycles -- as long as the LayerNorm launch it replaced);
 //  * the workgroup then walks over ALL N tiles (BN = 64 / 128 columns): W tiles stream HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, as
 //    gemm.hip) through ONE ring of NSTG stages of 64 k that runs across N-tile boundaries: the next tile's first stages are in flight
 //    while the current tile's epilogue runs, 5-7 stages (40-96 KiB) outstanding per CU; only B fragments are read from LDS
@@ -26,6 +30,8 @@
 // are not counted: an uncounted operation can only make a wait longer than necessary, never shorter.  The first version counted ring
 // stages only: every wait that followed an epilogue then also waited for that epilogue's store acknowledgements (~1.5 us per N tile).
 #include "gemm_args.h"
+
+#include <type_traits>
 
 namespace {
 using pcdm_gemm_detail::GemmArgs;
@@ -65,14 +71,23 @@ __device__ __forceinline__ void wait_stage(int n) {
 #endif
 }
 
+template <int N>
+__device__ __forceinline__ void wait_lds_keep() {   // s_waitcnt lgkmcnt(N): all but this wave's N most recent LDS operations are complete
+#ifndef PCDM_EMU
+    __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (N << 8) | (3 << 14));
+#endif
+}
+
 __device__ __forceinline__ void wait_lds_rg() {   // s_waitcnt lgkmcnt(0), visible to the compiler's scoreboard
 #ifndef PCDM_EMU
     __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));
 #endif
 }
 
-// WGM x WGN waves; a wave owns FMW row blocks of 16 and, per N tile, BN / WGN columns; NSTG ring stages of [BN][64]; LNF: LayerNorm on A
-template <int WGM, int WGN, int FMW, int BN, int NSTG, bool LNF>
+// WGM x WGN waves; a wave owns FMW row blocks of 16 and, per N tile, BN / WGN columns; NSTG ring stages of [BN][64]; LNF: folded LayerNorm;
+// GLU: the gated-linear-unit epilogue (its own instantiation: with all three epilogues in one kernel the lane constants hipcc hoists out of
+// the N-tile loop for each of them pushed the 48 x 64 wave tile over 256 VGPRs -- spills whose reloads sit behind the epilogue's stores)
+template <int WGM, int WGN, int FMW, int BN, int NSTG, bool LNF, bool GLU>
 __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * FMW * 16;
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     constexpr int DPW = BN / 8 / NW;       // LDS-DMA instructions per wave per stage (8 rows of 128 B each)
     constexpr int EPW = WNC + 4;           // fp32 pitch of the wave-private epilogue tile (16 rows)
     static_assert(NW == 8 && BN % (8 * NW) == 0 && WNC % 16 == 0 && (WNC == 32 || WNC == 64), "shape");
-    static_assert(NSTG >= 3 && (NSTG - 2) * DPW <= 14, "ring depth");
+    static_assert(NSTG >= 3 && (NSTG - 2) * DPW <= 14, "ring depth");   // (stages q + 1 .. q + NSTG - 2 in flight behind the one awaited)
     PCDM_DYN_SMEM(smem);
     u16* Ws = (u16*)smem;                                  // [NSTG][BN][64]  (unpadded, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
     float* eps_all = (float*)(Ws + NSTG * BN * 64);        // [NW][16][EPW]
@@ -91,6 +106,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WGN, wn = wave - wm * WGN;
+#ifndef PCDM_EMU
+    // p.debug & 4 (tools/rowgemm_anatomy.py): per-wave cycle accounting into ws[(workgroup, wave)][8] (uint64)
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool stamps = (p.debug & 4) != 0;
+#define RG_T0() do { if (stamps) tprev = __builtin_readcyclecounter(); } while (0)
+#define RG_ACC(i) do { if (stamps) { const unsigned long long n_ = __builtin_readcyclecounter(); tk[i] += n_ - tprev; tprev = n_; } } while (0)
+#else
+#define RG_T0() ((void)0)
+#define RG_ACC(i) ((void)0)
+#endif
+    RG_T0();
     const int m0 = blockIdx.x * BM + wm * (FMW * 16);      // first row of this wave
     const int lrow = lane & 15, lq = lane >> 4;            // fragment row / 8-element k chunk of the lane
     float* ep = eps_all + wave * (16 * EPW);
@@ -104,9 +130,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         b_off[i] = (uint32_t)((int64_t)rl * p.ldw * 2) + (uint32_t)(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
     }
     const int NT = p.Npad / BN;
+    float* wsum_s = bias_s + p.Npad;                       // [Npad] row sums of the gamma-folded weights (LNF)
+    float* stat_w = wsum_s + p.Npad + wave * (FMW * 16 * 2);   // [FMW * 16][2] {mean, rstd} of this wave's rows (LNF; kept out of registers)
     for (int i = t * 4; i < p.Npad; i += NW * 64 * 4) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         *(f32x4*)(bias_s + i) = p.bias ? *(const f32x4*)(p.bias + i) : z4;
+        if constexpr (LNF) *(f32x4*)(wsum_s + i) = *(const f32x4*)(p.ln_wsum + i);
     }
     const bool skip = m0 - wm * (FMW * 16) + BM <= p.zero_rows;   // every row of the workgroup is declared zero: epilogue only
     const int Q = skip ? 0 : NT * kNKT;
@@ -133,12 +162,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
             for (int ks = 0; ks < kKS; ++ks) xa[j][ks] = __builtin_bit_cast(u16x8, buf_load16(rs_a, v0 == kOOB ? kOOB : v0 + ks * 64));
         }
     }
+    // LayerNorm statistics of each row (4 lanes x 80 elements): mean, then the centred sum of squares (exact two-pass, fp32).  Lane
+    // (lrow, lq) ends up with the statistics of row 16 j + lrow -- the pixel row whose accumulators it holds in the epilogue.
     if constexpr (LNF) {
-        // LayerNorm over the 320 elements of each row (4 lanes x 80): mean, then the centred sum of squares (exact two-pass, fp32),
-        // then (x - mean) * rstd * gamma + beta rounded to bf16 -- the values pcdm_layernorm would have written to memory
-        float mean[FMW], rstd[FMW];
 #pragma unroll
         for (int j = 0; j < FMW; ++j) {
+            float mean_j, rstd_j;
             float s = 0.f;
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks)
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
                 for (int e = 0; e < 8; ++e) s += bf2f(xa[j][ks][e]);
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            mean[j] = s * (1.0f / kK);
+            mean_j = s * (1.0f / kK);
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks) RG_KEEP_PACKED(xa[j][ks]);
             float q = 0.f;
@@ -154,39 +183,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
             for (int ks = 0; ks < kKS; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = bf2f(xa[j][ks][e]) - mean[j];
+                    const float d = bf2f(xa[j][ks][e]) - mean_j;
                     q += d * d;
                 }
             q += __shfl_xor(q, 16, 64);
             q += __shfl_xor(q, 32, 64);
-            rstd[j] = 1.0f / sqrtf(q * (1.0f / kK) + p.ln_eps);
+            rstd_j = 1.0f / sqrtf(q * (1.0f / kK) + p.ln_eps);
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks) RG_KEEP_PACKED(xa[j][ks]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < kKS; ++ks) {
-            const int k = ks * 32 + 8 * lq;
-            const f32x4 g0 = *(const f32x4*)(p.ln_gamma + k), g1 = *(const f32x4*)(p.ln_gamma + k + 4);
-            const f32x4 c0 = *(const f32x4*)(p.ln_beta + k), c1 = *(const f32x4*)(p.ln_beta + k + 4);
-#pragma unroll
-            for (int j = 0; j < FMW; ++j) {
-                float y[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float g = e < 4 ? g0[e] : g1[e - 4], c = e < 4 ? c0[e] : c1[e - 4];
-                    y[e] = (bf2f(xa[j][ks][e]) - mean[j]) * rstd[j] * g + c;
-                }
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack2bf(y[2 * e], y[2 * e + 1]);
-                xa[j][ks] = __builtin_bit_cast(u16x8, o);
-                RG_KEEP_PACKED(xa[j][ks]);
+            if (lq == 0) {
+                stat_w[(j * 16 + lrow) * 2] = mean_j;
+                stat_w[(j * 16 + lrow) * 2 + 1] = rstd_j;
             }
         }
     }
 
+    RG_ACC(0);   // prologue: ring start, A rows, LayerNorm
     // ---- epilogue operands
-    const bool geglu = p.epilogue == PCDM_EPI_GEGLU;
+    constexpr bool geglu = GLU;
     const int vt0 = p.epilogue == PCDM_EPI_SPLIT_VT ? p.vt_col0 : 0x7fffffff;   // columns >= vt0 go to out2 transposed
     const int ncols_out = p.epilogue == PCDM_EPI_SPLIT_VT ? p.vt_col0 : (geglu ? p.N : p.N);
     const bool has_res = p.residual != nullptr && !geglu;
@@ -207,17 +221,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 
     // One N tile's results: lane holds, per (i, j), channels 16 i + 4 lq + {0..3} of pixel row 16 j + lrow.  Row block by row block:
     // quads -> ep[row][channel] (fp32) -> read back along the contiguous axis, 8 channels (or 8 tokens) per lane.
+    // accumulator quad (i, j) with the folded LayerNorm applied: rstd (acc - mean wsum[n])
+    auto ln_quad = [&](const f32x4& a, int n_quad, int j) -> f32x4 {
+        if constexpr (LNF) {
+            const f32x4 w4 = *(const f32x4*)(wsum_s + n_quad);
+            const float mean_j = stat_w[(j * 16 + lrow) * 2], rstd_j = stat_w[(j * 16 + lrow) * 2 + 1];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rstd_j * (a[e] - mean_j * w4[e]);
+            return v;
+        } else {
+            return a;
+        }
+    };
     auto epilogue = [&](int nt) {
         const int n0w = nt * BN + wn * WNC;                 // first (packed) column of this wave's tile
-        if (geglu) {
+        if constexpr (GLU) {
             if constexpr (WNC == 64) {
                 // packed rows alternate [32 h | 32 gate]: fragments 0, 1 = h, 2, 3 = gate of output channels n0w / 2 .. + 31
-                f32x4 bh[2], bg[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    bh[i] = *(const f32x4*)(bias_s + n0w + i * 16 + 4 * lq);
-                    bg[i] = *(const f32x4*)(bias_s + n0w + 32 + i * 16 + 4 * lq);
-                }
                 const bool swiglu = p.act == PCDM_ACT_SILU;   // (wave-uniform: one branch per row block, not one per element)
                 const int no = n0w / 2 + (lane & 3) * 8;    // read-back: 4 lanes per row, 16 rows per instruction
                 const int rr = lane >> 2;
@@ -226,12 +247,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         f32x4 v;
+                        const int nh = n0w + i * 16 + 4 * lq;      // packed column of h; its gate is 32 further (biases re-read from LDS
+                        const f32x4 ah = ln_quad(acc[i][j], nh, j) + *(const f32x4*)(bias_s + nh);        // per quad: registers are scarce here)
+                        const f32x4 ag = ln_quad(acc[i + 2][j], nh + 32, j) + *(const f32x4*)(bias_s + nh + 32);
                         if (swiglu) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][e] + bh[i][e]) * silu_f(acc[i + 2][j][e] + bg[i][e]);
+                            for (int e = 0; e < 4; ++e) v[e] = ah[e] * silu_f(ag[e]);
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][e] + bh[i][e]) * gelu_erf_f(acc[i + 2][j][e] + bg[i][e]);
+                            for (int e = 0; e < 4; ++e) v[e] = ah[e] * gelu_erf_f(ag[e]);
                         }
                         *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = v;
                     }
@@ -244,7 +268,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
                 }
             }
             return;
-        }
+        } else {
         if (n0w >= vt0) {
             // V^T: a lane takes one channel and 8 consecutive tokens; out2[b, channel, token]
 #pragma unroll
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
                 const int mb = m0 + j * 16;                 // 16 rows inside one batch entry (rows_per_batch % 16 == 0)
                 const int b = mb / p.rows_per_batch, tok0 = mb - b * p.rows_per_batch;
 #pragma unroll
-                for (int i = 0; i < FN; ++i) *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = acc[i][j];
+                for (int i = 0; i < FN; ++i) *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = ln_quad(acc[i][j], n0w + i * 16 + 4 * lq, j);
                 PCDM_WAVE_SYNC();
 #pragma unroll
                 for (int ii = 0; ii < WNC / 32; ++ii) {
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
 #pragma unroll
         for (int j = 0; j < FMW; ++j) {
 #pragma unroll
-            for (int i = 0; i < FN; ++i) *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = acc[i][j];
+            for (int i = 0; i < FN; ++i) *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = ln_quad(acc[i][j], n0w + i * 16 + 4 * lq, j);
             PCDM_WAVE_SYNC();
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
             }
             PCDM_WAVE_SYNC();
         }
+        }
     };
 
     // stores every epilogue is guaranteed to issue per wave (masked lanes / rows beyond M still issue the instruction)
@@ -318,66 +343,106 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         return;
     }
 
-    // ---- main loop: for every stage q: [wait: stage q landed, everybody done with stage q - 1] -> refill the freed slot with stage
-    // q + NSTG - 1 -> 2 k-steps of MFMAs from registers (A) x LDS (W).  The N-tile loop is a run-time loop, its 5 K-tiles are unrolled
-    // (the A fragments are indexed by compile-time k-step numbers: registers).
+    // ---- main loop.  Iteration q: [wait: stages <= q + 1 landed for the whole workgroup, everybody done reading stage q - 1] -> refill the
+    // freed slot with stage q + NSTG - 1 -> 2 k-steps of MFMAs from registers (A) x LDS (W).  The B fragments of a k-step are requested one
+    // k-step ahead, into the other of two register buffers (also across the stage boundary: that is what the one-stage-ahead wait is for),
+    // so their LDS latency is covered by the MFMAs in front of it -- in the first version every k-step waited out its own reads with
+    // the matrix pipe idle (tools/rowgemm_anatomy.py: 1450 cycles per stage for 770 cycles of MFMA issue on the SIMD).  Only the first
+    // k-step of an N tile, behind the epilogue, is exposed.  The N-tile loop is a run-time loop, its 5 K-tiles are unrolled (the A
+    // fragments are indexed by compile-time k-step numbers: registers).
     const int frow_sw = (lrow >> 1) & 7;
+    u16x8 wf[2][FN];
+    auto load_wf = [&](int q, int k2, auto bsel) {
+        constexpr int bb = decltype(bsel)::value;
+        const u16* ws = Ws + (q % NSTG) * (BN * 64) + (wn * WNC + lrow) * 64 + ((k2 * 4 + lq) ^ frow_sw) * 8;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[bb][i] = *(const u16x8*)(ws + i * 16 * 64);
+    };
+    auto mfma_step = [&](int ks, auto bsel) {
+        constexpr int bb = decltype(bsel)::value;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FMW; ++j) acc[i][j] = mfma_16x16x32(wf[bb][i], xa[j][ks], acc[i][j]);
+    };
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int kt = 0; kt < kNKT; ++kt) {
             const int q = nt * kNKT + kt;
-            // operations this wave may leave in flight: the younger ring stages q + 1 .. min(q + NSTG - 2, Q - 1), and the stores of
-            // the epilogues it ran since it issued stage q (in iteration lo = q - NSTG + 1, or in the prologue): an iteration i ends with
-            // an epilogue iff i % kNKT == kNKT - 1, so there are q / kNKT - lo / kNKT of them in [lo, q - 1]
-            const int younger = (Q - 1 - q) < (NSTG - 2) ? (Q - 1 - q) : (NSTG - 2);
-            const int lo = q - (NSTG - 1) > 0 ? q - (NSTG - 1) : 0;
+            // awaited stage: q + 1 (q itself at the very end).  Operations this wave may leave in flight: the ring stages younger than
+            // that, and the stores of the epilogues it ran since it issued the awaited stage (in iteration lo = target - NSTG + 1, or in
+            // the prologue): an iteration i ends with an epilogue iff i % kNKT == kNKT - 1: q / kNKT - lo / kNKT of them in [lo, q - 1]
+            const int tgt = q + 1 < Q ? q + 1 : q;
+            const int younger = (Q - 1 - tgt) < (NSTG - 2 - (tgt - q)) ? (Q - 1 - tgt) : (NSTG - 2 - (tgt - q));
+            const int lo = tgt - (NSTG - 1) > 0 ? tgt - (NSTG - 1) : 0;
+            RG_ACC(4);
             wait_stage(younger * DPW + (q / kNKT - lo / kNKT) * n_ep_stores);
+            RG_ACC(1);   // waiting for the stage / the other waves
             if (q + NSTG - 1 < Q) issue(q + NSTG - 1);
-            const u16* ws = Ws + (q % NSTG) * (BN * 64) + (wn * WNC + lrow) * 64;
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                u16x8 wf[FN];
-                const int co = ((k2 * 4 + lq) ^ frow_sw) * 8;
-#pragma unroll
-                for (int i = 0; i < FN; ++i) wf[i] = *(const u16x8*)(ws + i * 16 * 64 + co);
+            if (kt == 0) load_wf(q, 0, B0());            // (kt > 0: requested during the previous stage's second k-step)
+            // k-step 2 kt: request the fragments of k-step 2 kt + 1 (buffer 1), wait for buffer 0 only, multiply
+            load_wf(q, 1, B1());
+            wait_lds_keep<FN>();
+            PCDM_SCHED_BARRIER();
+            mfma_step(kt * 2, B0());
+            PCDM_SCHED_BARRIER();
+            // k-step 2 kt + 1: request the first fragments of the next stage (same N tile only), wait for buffer 1, multiply
+            if (kt + 1 < kNKT) {
+                load_wf(q + 1, 0, B0());
+                wait_lds_keep<FN>();
+            } else {
                 wait_lds_rg();
-                PCDM_SCHED_BARRIER();
-#pragma unroll
-                for (int i = 0; i < FN; ++i)
-#pragma unroll
-                    for (int j = 0; j < FMW; ++j) acc[i][j] = mfma_16x16x32(wf[i], xa[j][kt * 2 + k2], acc[i][j]);
-                PCDM_SCHED_BARRIER();
             }
+            PCDM_SCHED_BARRIER();
+            mfma_step(kt * 2 + 1, B1());
+            PCDM_SCHED_BARRIER();
+            RG_ACC(2);   // DMA issue + fragment reads + MFMAs
         }
         epilogue(nt);
         zero_acc();
+        RG_ACC(3);       // epilogue
     }
+#ifndef PCDM_EMU
+    if (stamps && p.ws && lane == 0) {
+        unsigned long long* o = (unsigned long long*)p.ws + ((int64_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = tk[i];
+    }
+#endif
 }
 
 template <int WGM, int WGN, int FMW, int BN, int NSTG>
 int launch_rg(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = WGM * FMW * 16, WNC = BN / WGN, NW = WGM * WGN;
     constexpr int smem_fixed = NSTG * BN * 64 * (int)sizeof(u16) + NW * 16 * (WNC + 4) * (int)sizeof(float);
-    if (a.Npad % BN || a.Npad > 4096) return -1;
-    const int smem = smem_fixed + a.Npad * (int)sizeof(float);   // + the bias vector
+    if (a.Npad % BN || a.Npad > 2560) return -1;
+    const int smem = smem_fixed + (2 * a.Npad + NW * FMW * 32) * (int)sizeof(float);   // + bias, the folded weights' row sums, row statistics
     if (a.epilogue == PCDM_EPI_GEGLU && WNC != 64) return -1;
     if (a.epilogue == PCDM_EPI_SPLIT_VT && (a.vt_col0 % WNC || a.rows_per_batch % 16 || (a.ldo2 & 7) || a.M % 16)) return -1;
     const int grid = (a.M + BM - 1) / BM;
-    if (a.ln_gamma) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_fixed + 4096 * (int)sizeof(float));
-            attr_done = true;
-        }
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, true>), dim3(grid), dim3(NW * 64), smem, st, a);
+    const int smem_max = smem_fixed + (2 * 2560 + NW * FMW * 32) * (int)sizeof(float);
+#define PCDM_RG_LAUNCH(LN_, GLU_)                                                                                                      \
+    do {                                                                                                                               \
+        static bool attr_done = false;                                                                                                 \
+        if (!attr_done) {                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, LN_, GLU_>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);                                          \
+            attr_done = true;                                                                                                          \
+        }                                                                                                                              \
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, LN_, GLU_>), dim3(grid), dim3(NW * 64), smem, st, a);     \
+    } while (0)
+    const bool glu = a.epilogue == PCDM_EPI_GEGLU;
+    if constexpr (WNC == 64) {
+        if (a.ln_wsum && glu) PCDM_RG_LAUNCH(true, true);
+        else if (a.ln_wsum) PCDM_RG_LAUNCH(true, false);
+        else if (glu) PCDM_RG_LAUNCH(false, true);
+        else PCDM_RG_LAUNCH(false, false);
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_fixed + 4096 * (int)sizeof(float));
-            attr_done = true;
-        }
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, false>), dim3(grid), dim3(NW * 64), smem, st, a);
+        if (a.ln_wsum) PCDM_RG_LAUNCH(true, false);
+        else PCDM_RG_LAUNCH(false, false);
     }
+#undef PCDM_RG_LAUNCH
     PCDM_CHECK_LAUNCH();
     return 0;
 }
@@ -391,12 +456,11 @@ int pcdm_gemm_detail::launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st
     if ((a.lda & 7) || (a.ldo & 7) || (a.N & 7) || (a.ldw & 7)) return -1;
     if (a.residual && ((a.ldr & 7) || a.res_mod < a.M)) return -1;
     if (a.epilogue == PCDM_EPI_GEGLU && (!a.bias || a.residual)) return -1;
-    if (a.ln_gamma && (!a.ln_beta || a.zero_rows)) return -1;
+    if (a.ln_wsum && a.zero_rows) return -1;
     switch (tile) {
         case 31: return launch_rg<4, 2, 3, 128, 6>(a, st);   // 192 rows, N tiles of 128 (waves 48 x 64: GEGLU-capable), 96 + 34 KiB
         case 32: return launch_rg<4, 2, 3, 64, 8>(a, st);    // 192 rows, N tiles of 64 (waves 48 x 32), 64 + 18 KiB
         case 33: return launch_rg<2, 4, 3, 128, 6>(a, st);   // 96 rows, N tiles of 128 (waves 48 x 32): M = 22528 -> 235 workgroups
-        case 34: return launch_rg<2, 4, 3, 256, 3>(a, st);   // 96 rows, N tiles of 256 (waves 48 x 64: GEGLU-capable), 96 + 34 KiB
         default: return -1;
     }
 }

@@ -113,6 +113,7 @@ class PackedWeight:
     cin: int = 0       # conv: (padded) input channels
     geglu: bool = False
     alg_nk: int = 0    # algorithmic N*K (un-padded; GEGLU counts both halves) for FLOP accounting
+    wsum: Optional[torch.Tensor] = None   # fp32 [Npad]: row sums of the packed bf16 weights when they carry a folded LayerNorm
 
 
 def pack_linear(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: int = 64) -> PackedWeight:
@@ -158,21 +159,49 @@ def pack_geglu(w: torch.Tensor, bias: torch.Tensor, device) -> PackedWeight:
     return PackedWeight(wp.to(BF16).to(device), bp.to(device), D, K, 2 * Dp, geglu=True, alg_nk=2 * D * K)
 
 
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm(x; gamma, beta) @ w^T + bias  ==  x_hat @ (w diag(gamma))^T + (bias + w beta)  with x_hat = (x - mean) rstd.
+    Returns (w diag(gamma), bias + w beta) in fp32."""
+    w, gamma, beta = w.float().cpu(), gamma.float().cpu(), beta.float().cpu()
+    b = w @ beta
+    if bias is not None:
+        b = b + bias.float().cpu()
+    return w * gamma[None, :], b
+
+
+def _with_wsum(pw: PackedWeight) -> PackedWeight:
+    pw.wsum = pw.w.float().sum(dim=1).contiguous()   # of the bf16 values the MFMA multiplies, in the packed row order
+    return pw
+
+
+def pack_linear_ln(w, bias, gamma, beta, device, pad_to: int = 64) -> PackedWeight:
+    """``pack_linear`` of a Linear that follows a LayerNorm, with the LayerNorm folded in (pcdm_gemm_params.ln_wsum)."""
+    wf, bf = fold_layernorm(w, bias, gamma, beta)
+    return _with_wsum(pack_linear(wf, bf, device, pad_to))
+
+
+def pack_geglu_ln(w, bias, gamma, beta, device) -> PackedWeight:
+    wf, bf = fold_layernorm(w, bias, gamma, beta)
+    return _with_wsum(pack_geglu(wf, bf, device))
+
+
 # ------------------------------------------------------------------------------------ GEMM / conv
 def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
          rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
-         ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+         ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None) -> torch.Tensor:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
-    ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  The A-in-registers kernel (tiles 31..34, K = 320) normalises
-    the rows while it loads them; for every other tile the rows go through ``pcdm_layernorm`` into ``ln_buf`` [M, K] first (the
-    tuner times both forms, the LayerNorm launch included, and keeps the faster)."""
+    ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  With ``pw_ln`` (the same Linear packed by ``pack_linear_ln`` /
+    ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..33, K = 320) needs no LayerNorm pass
+    at all -- it takes the row statistics from the rows it holds; for every other tile the rows go through ``pcdm_layernorm`` into
+    ``ln_buf`` [M, K] first (the tuner times both forms, the LayerNorm launch included, and keeps the faster)."""
     if ln is not None and conv is None and a2 is None and ln_buf is not None:
-        return _gemm_ln(a, pw, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0, tile=tile)
+        return _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0,
+                        tile=tile)
     assert ln is None
     p = GemmParams()
     assert a.dtype == BF16 and a.stride(-1) == 1 and (conv is None or a.is_contiguous())
@@ -246,8 +275,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     return out
 
 
-def _gemm_ln(a, pw, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile):
-    """LayerNorm + GEMM: fused into the A-in-registers kernel when that wins for the shape, two launches otherwise."""
+def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile):
+    """LayerNorm + GEMM: folded into the A-in-registers kernel when that wins for the shape, two launches otherwise."""
     gamma, beta, eps = ln
     M = a.shape[0]
     assert a.dtype == BF16 and a.stride(1) == 1 and a.shape[1] == pw.K and ln_buf.shape[0] >= M
@@ -258,15 +287,15 @@ def _gemm_ln(a, pw, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0,
     def fused(t):
         p = GemmParams()
         p.a, p.lda, p.c1 = _ptr(a), a.stride(0), a.shape[1]
-        p.w, p.M, p.N, p.K, p.Npad = _ptr(pw.w), M, pw.N, pw.K, pw.Npad
-        p.bias = _ptr(pw.bias) if pw.bias is not None else None
+        p.w, p.M, p.N, p.K, p.Npad = _ptr(pw_ln.w), M, pw_ln.N, pw_ln.K, pw_ln.Npad
+        p.bias = _ptr(pw_ln.bias)
         p.rows_per_batch = rows_per_batch or M
         p.epilogue, p.vt_col0 = epilogue, vt_col0
         p.out = _ptr(out)
         p.ldo = out.stride(0)
         if out2 is not None:
             p.out2, p.ldo2 = _ptr(out2), out2.shape[-1]
-        p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(_c(gamma, torch.float32)), _ptr(_c(beta, torch.float32)), float(eps)
+        p.ln_wsum, p.ln_eps = _ptr(_c(pw_ln.wsum, torch.float32)), float(eps)
         p.tile = t
         return _lib.lib().pcdm_gemm(C.byref(p), stream)
 
@@ -274,6 +303,10 @@ def _gemm_ln(a, pw, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0,
         n = layernorm(a, gamma, beta, eps, ln_buf[:M])
         return gemm(n, pw, out, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0)
 
+    if pw_ln is None or pw_ln.wsum is None:
+        assert not tile
+        two_launches()
+        return out
     if choice is None and AUTOTUNE and a.is_cuda and pw.K == 320 and not torch.cuda.is_current_stream_capturing():
         two_launches()                         # (tunes the plain GEMM of this shape on the way)
         ref = out.float().clone()
@@ -291,7 +324,7 @@ def _gemm_ln(a, pw, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0,
         for t in ROWGEMM_TILES:
             if fused(t) != 0:
                 continue
-            if not bool(((out.float() - ref).abs().max() <= 2e-2 * ref.abs().max() + 1e-3).item()):
+            if not bool(((out.float() - ref).abs().max() <= 3e-2 * ref.abs().max() + 1e-3).item()):
                 continue
             tt = timed(lambda: fused(t))
             if tt < best_t:
@@ -303,23 +336,23 @@ def _gemm_ln(a, pw, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0,
         if LAUNCH_LOG is not None and a.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _chk(fused(choice), "pcdm_gemm (LayerNorm fused)")
+            _chk(fused(choice), "pcdm_gemm (LayerNorm folded)")
             e1.record()
             LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, False, choice, 1), 2.0 * M * pw.alg_nk))
         else:
-            _chk(fused(choice), "pcdm_gemm (LayerNorm fused)")
+            _chk(fused(choice), "pcdm_gemm (LayerNorm folded)")
         return out
     two_launches()
     return out
 
 
-ROWGEMM_TILES = (31, 32, 33, 34)   # rowgemm.hip (K = 320): id -> (BM, BN) below
+ROWGEMM_TILES = (31, 32, 33)   # rowgemm.hip (K = 320): id -> (BM, BN) below
 # gemm.hip dispatch_tile(): id -> (BM, BN)
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),
                15: (128, 64), 16: (512, 64), 17: (256, 256), 18: (128, 128),
                21: (192, 320), 26: (192, 256),
-               31: (192, 128), 32: (192, 64), 33: (96, 128), 34: (96, 256)}
+               31: (192, 128), 32: (192, 64), 33: (96, 128)}
 _TUNED: dict = {}
 _WS: dict = {}
 

@@ -352,6 +352,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             a["o2"] = lin(b + "attn2.to_out.0.")
             a["ff1"] = ops.pack_geglu(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"], dev)
             a["ff2"] = lin(b + "ff.net.2.")
+            if c == 320:   # K = 320: the A-in-registers kernel can take these three with their LayerNorm folded into the weights
+                ln = [(sd[b + f"norm{i}.weight"], sd[b + f"norm{i}.bias"]) for i in (1, 2, 3)]
+                a["qkv_ln"] = ops.pack_linear_ln(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"],
+                                                            sd[b + "attn1.to_v.weight"]], 0), None, ln[0][0], ln[0][1], dev)
+                a["q2_ln"] = ops.pack_linear_ln(sd[b + "attn2.to_q.weight"], None, ln[1][0], ln[1][1], dev)
+                a["ff1_ln"] = ops.pack_geglu_ln(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"], ln[2][0], ln[2][1], dev)
             w[p] = a
         for i in range(len(self._boc) - 1):
             w[f"down_blocks.{i}.downsamplers.0.conv."] = conv(f"down_blocks.{i}.downsamplers.0.conv.")
@@ -560,12 +566,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
             t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)))
             # self-attention
-            # LayerNorm -> projection pairs go through ops.gemm(ln=...): at K = 320 (level 0) the A-in-registers kernel normalises the
-            # rows while loading them (no LayerNorm launch, no normalised tensor in memory); elsewhere LayerNorm runs first into "ln"
+            # LayerNorm -> projection pairs go through ops.gemm(ln=...): at K = 320 (level 0) the A-in-registers kernel takes the weights
+            # with the LayerNorm folded in (no LayerNorm launch, no normalised tensor anywhere); elsewhere LayerNorm runs first into "ln"
             qk = self._buf("qk", (M, 2 * c))
             vt = self._buf("vt", (B, c, (HW_ + 7) // 8 * 8), zero=True)
             ops.gemm(t0, a["qkv"], qk, rows_per_batch=HW_, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * c,
-                     ln=(a["ln1"][0], a["ln1"][1], 1e-5), ln_buf=self._buf("ln", (M, c)))
+                     ln=(a["ln1"][0], a["ln1"][1], 1e-5), ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("qkv_ln"))
             if self._attn_fp8:
                 HW16 = (HW_ + 15) // 16 * 16
                 k8 = ops.quantize_fp8(qk[:, c:], self._buf("k8", (M, c), ops.FP8))
@@ -579,14 +585,14 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             # the to_out GEMM as zero A rows (no main loop for tiles that lie entirely inside them)
             r0 = nzero * HW_
             q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
-                          ln_buf=self._buf("ln", (M, c))[r0:])
+                          ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"))
             k2, vt2 = kv[p]
             at2 = self._buf("at", (M, c))
             (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
             t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0)
             # GEGLU feed-forward
             ff = ops.gemm(t2, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU, ln=(a["ln3"][0], a["ln3"][1], 1e-5),
-                          ln_buf=self._buf("ln", (M, c)))
+                          ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("ff1_ln"))
             t3 = ops.gemm(ff, a["ff2"], self._buf("t1", (M, c)), residual=t2, res_mod=M)
             return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M)
 

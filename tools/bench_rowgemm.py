@@ -32,11 +32,15 @@ def main():
         a = (torch.randn(M, K, generator=g) * 1.0).to(BF16).to(dev)
         if epi == ops.EPI_GEGLU:
             w = torch.randn(2 * N, K, generator=g) / math.sqrt(K)
-            pw = ops.pack_geglu(w, torch.randn(2 * N, generator=g) * 0.5, dev)
+            bb = torch.randn(2 * N, generator=g) * 0.5
+            pw = ops.pack_geglu(w, bb, dev)
+            pw_ln = ops.pack_geglu_ln(w, bb, gamma.cpu(), beta.cpu(), dev)
             flops = 2.0 * M * 2 * N * K
         else:
             w = torch.randn(N, K, generator=g) / math.sqrt(K)
-            pw = ops.pack_linear(w, torch.randn(N, generator=g) if epi == ops.EPI_STORE else None, dev)
+            bb = torch.randn(N, generator=g) if epi == ops.EPI_STORE else None
+            pw = ops.pack_linear(w, bb, dev)
+            pw_ln = ops.pack_linear_ln(w, bb, gamma.cpu(), beta.cpu(), dev)
             flops = 2.0 * M * N * K
         res = torch.randn(M, N, generator=g).to(BF16).to(dev) if use_res else None
         kw = dict(epilogue=epi)
@@ -59,7 +63,7 @@ def main():
                 continue
             def f(t=t):
                 if use_ln:
-                    ops.gemm(a, pw, out, tile=t, ln=(gamma, beta, 1e-5), ln_buf=lnb, **{k: v for k, v in kw.items() if k not in ("residual", "res_mod")})
+                    ops.gemm(a, pw, out, tile=t, ln=(gamma, beta, 1e-5), ln_buf=lnb, pw_ln=pw_ln, **{k: v for k, v in kw.items() if k not in ("residual", "res_mod")})
                 else:
                     ops.gemm(a, pw, out, tile=t, **kw)
             try:
@@ -76,7 +80,7 @@ def main():
             f()
             torch.cuda.synchronize()
             err = ((out.float() - ref).norm() / ref.norm()).item()
-            assert err < 2e-2, (k, err)
+            assert err < 3e-2, (k, err)
         for _ in range(7):
             for k, f in variants.items():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
