@@ -47,7 +47,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
         o = LIBDIR / (src + ".o")
         if force or _stale(o, [s, *headers, *[CSRC / d for d in EXTRA_DEPS.get(src, [])]]):
             jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-                         *([] if src in NO_VGPR_FORM else VGPR_FORM), "-Wno-unused-result", "-c", str(s), "-o", str(o)])
+                         *([] if src in NO_VGPR_FORM else VGPR_FORM), "-Wno-unused-result",
+                         *(["-D" + d for d in os.environ.get("PCDM_BUILD_DEFINES", "").split()]), "-c", str(s), "-o", str(o)])
         objs.append(str(o))
     if jobs:   # the translation units are independent: compile them side by side (gemm.hip alone is ~1 min)
         from concurrent.futures import ThreadPoolExecutor

@@ -659,6 +659,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         // residual rows of ALL passes -> registers, before the first store (see above)
 #pragma unroll
         for (int q = 0; q < (RES ? NCG * NJB : 1); ++q) issue_res(q);
+        const bool swiglu = p.act == PCDM_ACT_SILU;
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;          // bias of this lane's 8 channels: re-read (LDS) once per column group
 #pragma unroll
         for (int q = 0; q < NCG * NJB; ++q) {
@@ -686,8 +687,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                                 const acc_t& ah = acc[i][jb * RB + jj];
                                 const acc_t& ag = acc[i + FN / 2][jb * RB + jj];
                                 f32x4 v;
+                                if (swiglu) {   // (one wave-uniform branch per quad: with gate_act(., p.act) hipcc branched per element)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * gate_act(ag[4 * rg + e] + bg[e], p.act);
+                                    for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * silu_f(ag[4 * rg + e] + bg[e]);
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * gelu_erf_f(ag[4 * rg + e] + bg[e]);
+                                }
                                 *(f32x4*)(ep + (jj * F + prow) * EPW + nl) = v;
                             }
                 }

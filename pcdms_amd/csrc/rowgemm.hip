@@ -49,11 +49,10 @@ constexpr uint32_t kOOB = 0x80000000u;
 #define RG_KEEP_PACKED(v) asm volatile("" : "+v"(v))
 #endif
 
-// s_waitcnt vmcnt(n) + lgkmcnt(0), then s_barrier; n is wave-uniform at run time (a scalar switch over immediates)
+// s_waitcnt vmcnt(n) + lgkmcnt(0) (the stage barrier follows); n is wave-uniform at run time (a scalar switch over immediates)
 __device__ __forceinline__ void wait_stage(int n) {
 #ifdef PCDM_EMU
     (void)n;
-    __syncthreads();
 #else
     __builtin_amdgcn_sched_barrier(0);
     // simm16: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
@@ -66,6 +65,15 @@ __device__ __forceinline__ void wait_stage(int n) {
         default: __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8) | (0 << 14)); break;
     }
 #undef PCDM_RG_W
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+__device__ __forceinline__ void stage_barrier() {
+#ifdef PCDM_EMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -130,6 +138,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         b_off[i] = (uint32_t)((int64_t)rl * p.ldw * 2) + (uint32_t)(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
     }
     const int NT = p.Npad / BN;
+    // Every workgroup walks ALL N tiles, i.e. streams the whole of W -- and with one workgroup per CU starting together they would all ask
+    // the L2s for the SAME 16 KiB at the same moment, stage after stage (one channel serving a line 32 times over while the others idle).
+    // Each workgroup therefore starts its walk at a different N tile (p.debug & 16: all start at tile 0, for A/B runs).
+    const int rot = (p.debug & 16) ? 0 : (int)((blockIdx.x * 7u) % (unsigned)NT);
     float* wsum_s = bias_s + p.Npad;                       // [Npad] row sums of the gamma-folded weights (LNF)
     float* stat_w = wsum_s + p.Npad + wave * (FMW * 16 * 2);   // [FMW * 16][2] {mean, rstd} of this wave's rows (LNF; kept out of registers)
     for (int i = t * 4; i < p.Npad; i += NW * 64 * 4) {
@@ -140,7 +152,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     const bool skip = m0 - wm * (FMW * 16) + BM <= p.zero_rows;   // every row of the workgroup is declared zero: epilogue only
     const int Q = skip ? 0 : NT * kNKT;
     auto issue = [&](int q) {
-        const int nt = q / kNKT, kt = q - nt * kNKT;
+        const int nt_ = q / kNKT, kt = q - nt_ * kNKT;
+        const int nt = nt_ + rot < NT ? nt_ + rot : nt_ + rot - NT;
         const uint32_t soff = (uint32_t)(((int64_t)nt * BN * p.ldw + kt * 64) * 2);
         u16* ws = Ws + (q % NSTG) * (BN * 64) + (wave * DPW) * 8 * 64;
 #pragma unroll
@@ -204,7 +217,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     const int vt0 = p.epilogue == PCDM_EPI_SPLIT_VT ? p.vt_col0 : 0x7fffffff;   // columns >= vt0 go to out2 transposed
     const int ncols_out = p.epilogue == PCDM_EPI_SPLIT_VT ? p.vt_col0 : (geglu ? p.N : p.N);
     const bool has_res = p.residual != nullptr && !geglu;
-    const BufRsrc rs_o = make_buf_rsrc(p.out, (uint32_t)((((int64_t)p.M - 1) * p.ldo + ncols_out) * 2));
+    // (p.debug & 32, tools/rowgemm_anatomy.py: a zero-size output descriptor -- every store is issued and dropped)
+    const BufRsrc rs_o = make_buf_rsrc(p.out, (p.debug & 32) ? 0u : (uint32_t)((((int64_t)p.M - 1) * p.ldo + ncols_out) * 2));
     const BufRsrc rs_r = make_buf_rsrc(has_res ? (const void*)p.residual : (const void*)p.out,
                                        has_res ? (uint32_t)((((int64_t)p.M - 1) * p.ldr + p.N) * 2) : 0u);
     const BufRsrc rs_vt = make_buf_rsrc(p.out2 ? (const void*)p.out2 : (const void*)p.out,
@@ -234,7 +248,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
             return a;
         }
     };
-    auto epilogue = [&](int nt) {
+    auto epilogue = [&](int nt_) {
+        const int nt = nt_ + rot < NT ? nt_ + rot : nt_ + rot - NT;
         const int n0w = nt * BN + wn * WNC;                 // first (packed) column of this wave's tile
         if constexpr (GLU) {
             if constexpr (WNC == 64) {
@@ -379,8 +394,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
             const int lo = tgt - (NSTG - 1) > 0 ? tgt - (NSTG - 1) : 0;
             RG_ACC(4);
             wait_stage(younger * DPW + (q / kNKT - lo / kNKT) * n_ep_stores);
-            RG_ACC(1);   // waiting for the stage / the other waves
-            if (q + NSTG - 1 < Q) issue(q + NSTG - 1);
+            RG_ACC(1);   // waiting for this wave's part of the stage to land
+            stage_barrier();
+            RG_ACC(5);   // waiting for the other waves
+            // The two waves of a SIMD (w and w + 4) place the refill at opposite ends of the iteration: an LDS-DMA instruction costs its wave
+            // ~175 cycles of issue (tools/rowgemm_anatomy.py: 350 per stage with both waves doing it right behind the barrier, the matrix
+            // pipe idle), so one wave issues while its partner multiplies, then they swap (p.debug & 64: both in front, for A/B runs)
+            const bool dma_first = wave < NW / 2 || (p.debug & 64);
+            if (dma_first && q + NSTG - 1 < Q) issue(q + NSTG - 1);
+            RG_ACC(4);   // DMA issue
             if (kt == 0) load_wf(q, 0, B0());            // (kt > 0: requested during the previous stage's second k-step)
             // k-step 2 kt: request the fragments of k-step 2 kt + 1 (buffer 1), wait for buffer 0 only, multiply
             load_wf(q, 1, B1());
@@ -398,7 +420,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
             PCDM_SCHED_BARRIER();
             mfma_step(kt * 2 + 1, B1());
             PCDM_SCHED_BARRIER();
-            RG_ACC(2);   // DMA issue + fragment reads + MFMAs
+            if (!dma_first && q + NSTG - 1 < Q) issue(q + NSTG - 1);
+            RG_ACC(2);   // fragment reads + MFMAs (+ the late DMA issue)
         }
         epilogue(nt);
         zero_acc();
@@ -461,6 +484,10 @@ int pcdm_gemm_detail::launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st
         case 31: return launch_rg<4, 2, 3, 128, 6>(a, st);   // 192 rows, N tiles of 128 (waves 48 x 64: GEGLU-capable), 96 + 34 KiB
         case 32: return launch_rg<4, 2, 3, 64, 8>(a, st);    // 192 rows, N tiles of 64 (waves 48 x 32), 64 + 18 KiB
         case 33: return launch_rg<2, 4, 3, 128, 6>(a, st);   // 96 rows, N tiles of 128 (waves 48 x 32): M = 22528 -> 235 workgroups
+#ifdef PCDM_DEV_ROWGEMM_VARIANTS
+        case 35: return launch_rg<4, 2, 3, 128, 4>(a, st);   // as 31 with a 4-stage ring
+        case 36: return launch_rg<4, 2, 3, 128, 3>(a, st);   // as 31 with a 3-stage ring
+#endif
         default: return -1;
     }
 }

@@ -17,7 +17,7 @@ lib = _lib.lib()
 BF16 = torch.bfloat16
 
 
-def run(name, M, N, tile, epi, ln):
+def run(name, M, N, tile, epi, ln, extra=0):
     K = 320
     g = torch.Generator().manual_seed(0)
     a = torch.randn(M, K, generator=g).to(BF16).to(dev)
@@ -27,7 +27,7 @@ def run(name, M, N, tile, epi, ln):
     else:
         pw = ops._with_wsum(ops.pack_linear(torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g), dev))
         flops = 2.0 * M * N * K
-    bm = ops.TILE_SHAPES[tile][0]
+    bm = ops.TILE_SHAPES.get(tile, (192, 128))[0]
     nwg = -(-M // bm)
     ws = torch.zeros(max(nwg, (M + 95) // 96) * 8 * 8, dtype=torch.int64, device=dev)
     p = _lib.GemmParams()
@@ -52,7 +52,7 @@ def run(name, M, N, tile, epi, ln):
     st = torch.cuda.current_stream().cuda_stream
     times = {}
     for flag in (0, 4):
-        p.tile = tile | (flag << 8)
+        p.tile = tile | ((flag | extra) << 8)
         for _ in range(3):
             rc = lib.pcdm_gemm(C.byref(p), st)
             assert rc == 0, rc
@@ -66,15 +66,17 @@ def run(name, M, N, tile, epi, ln):
         times[flag] = e0.elapsed_time(e1) / 10 * 1e3
     s = ws.view(-1, 8)[: nwg * 8].cpu().double()
     s = s[s[:, 2] > 0]
-    med = [s[:, i].median().item() for i in range(5)]
+    med = [s[:, i].median().item() for i in range(6)]
     tot = sum(med)
-    print(f"{name} M{M} N{N} tile {tile} ln={ln}: {times[0]:.1f} us ({flops / times[0] / 1e6:.0f} TF/s); stamped {times[4]:.1f} us; per wave median cycles: "
-          f"prologue {med[0]:.0f} | stage wait {med[1]:.0f} | issue+reads+MFMA {med[2]:.0f} | epilogue {med[3]:.0f} | loop overhead {med[4]:.0f} | "
+    print(f"{name} M{M} N{N} tile {tile} ln={ln} dbg={extra}: {times[0]:.1f} us ({flops / times[0] / 1e6:.0f} TF/s); stamped {times[4]:.1f} us; per wave median cycles: "
+          f"prologue {med[0]:.0f} | vmcnt wait {med[1]:.0f} | barrier {med[5]:.0f} | DMA issue + loop {med[4]:.0f} | reads+MFMA {med[2]:.0f} | epilogue {med[3]:.0f} | "
           f"sum {tot:.0f} (= {tot / times[4] / 1e3:.2f} cycles/ns)")
 
 
 if __name__ == "__main__":
     run("ff1 ", 45056, 1280, 31, ops.EPI_GEGLU, True)
+    run("ff1 dma-both-first", 45056, 1280, 31, ops.EPI_GEGLU, True, 64)
+    run("lin dma-both-first", 45056, 2560, 31, ops.EPI_STORE, False, 64)
     run("ff1 ", 45056, 1280, 31, ops.EPI_GEGLU, False)
     run("qkv ", 45056, 960, 32, ops.EPI_SPLIT_VT, True)
     run("q2  ", 22528, 320, 32, ops.EPI_STORE, True)
