@@ -472,7 +472,7 @@ def load_tuning(path: Path = TUNING_FILE) -> int:
 
 def save_tuning(path: Path = TUNING_FILE, note: str = "") -> None:
     Path(path).parent.mkdir(parents=True, exist_ok=True)
-    tab = {"note": note, "gemm": {",".join(str(x) for x in k): list(v) for k, v in sorted(_TUNED.items())}}
+    tab = {"note": note, "gemm": {",".join(str(x) for x in k): list(v) for k, v in sorted(_TUNED.items(), key=lambda kv: str(kv[0]))}}
     Path(path).write_text(json.dumps(tab, indent=0))
 
 
