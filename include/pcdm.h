@@ -196,6 +196,62 @@ int pcdm_lincomb(float* y, int nin, const float* const* xs, const float* c, int6
 /* *step_dev += 1 */
 int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s);
 
+/* ---- The UNet forward as ONE entry ("a fused unet_forward(ctx, ...)" over an opaque context).
+ * Replaces Stage2_InapintUNet2DConditionModel.forward (/root/reference/src/models/stage2_inpaint_unet_2d_condition.py:579-825) for a host
+ * that is not Python: pcdm_unet_create from the topology, pcdm_unet_set_weight / _set_vector with the packed tensors under their
+ * diffusers module paths, ONE caller-owned workspace (pcdm_unet_workspace_bytes, zeroed once by pcdm_unet_workspace_init), then per
+ * sampling call pcdm_unet_prepare_conditioning (class embedding, pose feature, cross-attention K / V^T: step-invariant) and per denoise
+ * step pcdm_unet_forward.  No allocation inside, every launch on the caller's stream, fixed scratch addresses (hipGraph-capturable).
+ * Weight names (N = diffusers module path, e.g. "down_blocks.0.resnets.1." / "...attentions.0."):
+ *   conv_in, conv_out, N"conv1", N"conv2", N"conv_shortcut", "down_blocks.i.downsamplers.0.conv", "up_blocks.i.upsamplers.0.conv"  (pcdm_pack conv3x3 / linear)
+ *   N"proj_in", N"proj_out", N"qkv" (to_q|to_k|to_v rows), N"o1", N"q2", N"kv2" (to_k|to_v of attn2), N"o2", N"ff1" (GEGLU packing), N"ff2",
+ *   optional N"qkv_ln" / N"q2_ln" / N"ff1_ln" (LayerNorm folded, with wsum), "time_emb_proj" (all resnets' rows concatenated in resnet order),
+ *   "time_embedding.linear_1/2", "class_embedding.linear_1/2" (bf16 [N, K] unpadded + fp32 bias, for pcdm_small_linear)
+ * Vectors (fp32): N"norm1.weight" / ".bias", N"norm2.*" (resnets), N"norm.*" and N"transformer_blocks.0.norm{1,2,3}.*" (transformers),
+ *   "conv_norm_out.weight" / ".bias".
+ * Tile hints (optional, pcdm_unet_set_tile): the (tile, split_k) pcdm_gemm should use for a problem key; without one the library heuristic.
+ * Return codes as everywhere; pcdm_unet_last_error names the missing weight / failing call. */
+typedef struct pcdm_unet pcdm_unet;
+typedef struct pcdm_unet_config {
+    int32_t out_channels;
+    int32_t n_levels;               /* <= 8 */
+    int32_t block_out_channels[8];  /* multiples of 64; heads[i] * 64 == block_out_channels[i] */
+    int32_t heads[8];
+    int32_t cross_attn[8];          /* down block i is CrossAttnDownBlock2D (up block n-1-i mirrors it) */
+    int32_t layers_per_block;
+    int32_t cross_attention_dim;
+    int32_t norm_groups;
+    float norm_eps;
+    int32_t class_embed;            /* 1: "projection" class embedding (stage 2), 0: none (stage 3) */
+    int32_t flip_sin_to_cos;
+    float freq_shift;
+} pcdm_unet_config;
+pcdm_unet* pcdm_unet_create(const pcdm_unet_config* cfg);
+void pcdm_unet_destroy(pcdm_unet* u);
+const char* pcdm_unet_last_error(const pcdm_unet* u);
+int pcdm_unet_set_weight(pcdm_unet* u, const char* name, const void* w_bf16, const float* bias, const float* wsum, int N, int K, int Npad, int cin);
+int pcdm_unet_set_vector(pcdm_unet* u, const char* name, const float* v, int n);
+int pcdm_unet_set_tile(pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source, int residual,
+                       int zero_rows, int tile, int split_k);
+int64_t pcdm_unet_workspace_bytes(pcdm_unet* u, int B, int h, int w, int L);
+int pcdm_unet_workspace_init(pcdm_unet* u, int B, int h, int w, int L, void* workspace, pcdm_stream_t s);
+/* ehs fp32 [B, L, cross_attention_dim]; class_labels fp32 [B, K of class_embedding.linear_1] or NULL; pose fp32 NCHW [pose_b = 1 | B, C0, h, w] or
+ * NULL; zero_ctx_batches: leading batch entries of ehs that are all-zero (the CFG unconditional half: their cross-attention is skipped) */
+int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w, int L, const float* ehs, const float* class_labels, const float* pose, int pose_b,
+                                   int zero_ctx_batches, void* workspace, pcdm_stream_t s);
+/* x_in NHWC bf16 [B, h, w, conv_in.cin] (pcdm_assemble_input / pcdm_nchw_f32_to_nhwc_bf16); timestep = t_dev[step_dev ? *step_dev : 0] (device);
+ * pose_b as passed to prepare_conditioning (0: no pose); eps_out fp32 NCHW [B, out_channels, h, w] */
+int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* t_dev, const int32_t* step_dev, int B, int h, int w, int L, int pose_b,
+                      void* workspace, float* eps_out, pcdm_stream_t s);
+/* Host-side weight packing (plain loops on HOST memory; upload the result): the layouts pcdm_gemm / pcdm_unet_set_weight expect, from the
+ * fp32 tensors of a diffusers state dict.  Each returns Npad (< 0: bad arguments); output pointers may be NULL to query sizes.
+ *   pcdm_pack_linear : [N, K] -> bf16 [Npad, K], bias -> fp32 [Npad]                       (Npad = N rounded up to pad_to, normally 64)
+ *   pcdm_pack_conv3x3: [N, Cin, 3, 3] -> bf16 [Npad, 9 Cp], k = (ky 3 + kx) Cp + c          (Cp = Cin rounded up to 64; *K_out = 9 Cp, *cin_out = Cp)
+ *   pcdm_pack_geglu  : [2 D, K] rows [h | gate] -> bf16 [2 Dp, K], rows per 64 = [32 h | 32 gate], bias likewise (GEMM N = D, Npad = 2 Dp) */
+int pcdm_pack_linear(const float* w, const float* bias, int N, int K, int pad_to, uint16_t* out_w, float* out_bias);
+int pcdm_pack_conv3x3(const float* w, const float* bias, int N, int Cin, int pad_to, uint16_t* out_w, float* out_bias, int* K_out, int* cin_out);
+int pcdm_pack_geglu(const float* w, const float* bias, int D, int K, uint16_t* out_w, float* out_bias);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,15 @@ class GemmParams(C.Structure):
     ]
 
 
+class UNetConfig(C.Structure):
+    """Mirror of ``pcdm_unet_config`` (include/pcdm.h)."""
+
+    _fields_ = [("out_channels", C.c_int32), ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * 8), ("heads", C.c_int32 * 8),
+                ("cross_attn", C.c_int32 * 8), ("layers_per_block", C.c_int32), ("cross_attention_dim", C.c_int32),
+                ("norm_groups", C.c_int32), ("norm_eps", C.c_float), ("class_embed", C.c_int32), ("flip_sin_to_cos", C.c_int32),
+                ("freq_shift", C.c_float)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "pcdm_version": ([], C.c_int),
@@ -73,6 +82,19 @@ _SIGS = {
     "pcdm_gaussian_sample": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_image_to_uint8": ([_P, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_advance_step": ([_P, _P], C.c_int),
+    "pcdm_unet_create": ([C.POINTER(UNetConfig)], _P),
+    "pcdm_unet_destroy": ([_P], None),
+    "pcdm_unet_last_error": ([_P], C.c_char_p),
+    "pcdm_unet_set_weight": ([_P, C.c_char_p, _P, _P, _P, _I, _I, _I, _I], C.c_int),
+    "pcdm_unet_set_vector": ([_P, C.c_char_p, _P, _I], C.c_int),
+    "pcdm_unet_set_tile": ([_P] + [_I] * 13, C.c_int),
+    "pcdm_unet_workspace_bytes": ([_P, _I, _I, _I, _I], _L),
+    "pcdm_unet_workspace_init": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "pcdm_unet_prepare_conditioning": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P], C.c_int),
+    "pcdm_unet_forward": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "pcdm_pack_linear": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),
+    "pcdm_pack_conv3x3": ([_P, _P, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "pcdm_pack_geglu": ([_P, _P, _I, _I, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 

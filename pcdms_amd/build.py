@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libpcdm.so"
-SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip", "unet_ctx.hip"]
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]   # MFMA accumulators in arch VGPRs (no v_accvgpr moves)
 NO_VGPR_FORM: set = set()
 EXTRA_DEPS: dict = {}

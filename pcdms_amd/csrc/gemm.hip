@@ -369,6 +369,33 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4 * NQ; ++r) acc[i][j][r] = 0.f;
 
+    // Wave tiles whose residual rows fit 32 VGPRs (64x32 / 32x64 / 64x64: the tiles the thin-K linears with a residual run on) request
+    // them HERE, in front of the K loop: they do not depend on it, and loaded in the epilogue they are a full HBM round trip in front
+    // of its first store (tools/gemm_anatomy.py: 16 k cycles of epilogue with a residual against 8 k without, on a 14 k-cycle K loop).
+    constexpr int E_CG = FN < 64 / F ? FN : 64 / F;                          // fragment columns per epilogue pass (= CG below)
+    constexpr int E_NPASS = ((FN + E_CG - 1) / E_CG) * (WM / 32);            // epilogue passes of the wave tile
+    constexpr bool EARLY_RES = !CONV && E_NPASS * 16 <= 32;
+    u32x4 rv_early[EARLY_RES ? E_NPASS : 1][4];
+    bool early_res = false;
+    if constexpr (EARLY_RES) {
+        early_res = p.residual != nullptr && p.split_k <= 1 && p.epilogue == PCDM_EPI_STORE && p.act == 0 && (p.N & 7) == 0 && (p.ldo & 7) == 0 &&
+                    (p.ldr & 7) == 0 && p.res_mod >= p.M && (!p.rowvec || p.rows_per_batch >= 32);
+        if (early_res) {
+            const BufRsrc rs_r0 = make_buf_rsrc(p.residual, (uint32_t)((((int64_t)p.M - 1) * p.ldr + p.N) * 2));
+#pragma unroll
+            for (int q = 0; q < E_NPASS; ++q) {
+                constexpr int NJB_ = WM / 32;
+                const int i0 = (q / NJB_) * E_CG;
+                const int wc = ((FN - i0) < E_CG ? (FN - i0) : E_CG) * F;
+                const int mrow0 = m0 + wm * WM + (q % NJB_) * 32, nc = n0 + wn * WN + i0 * F;
+                if (wc == 64) lean_res_load<64>(p, lane, mrow0, nc, rs_r0, rv_early[q]);
+                else if (wc == 32) lean_res_load<32>(p, lane, mrow0, nc, rs_r0, rv_early[q]);
+                else if (wc == 16) lean_res_load<16>(p, lane, mrow0, nc, rs_r0, rv_early[q]);
+                else lean_res_load<48>(p, lane, mrow0, nc, rs_r0, rv_early[q]);
+            }
+        }
+    }
+
     const int nkt_all = p.K / BK;
     kt0 = (int)((int64_t)ksplit * nkt_all / p.split_k);
     int nkt = (int)((int64_t)(ksplit + 1) * nkt_all / p.split_k) - kt0;  // this workgroup's K-tiles
@@ -656,9 +683,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
             else if (wc == 16) lean_res_load<16>(p, lane, mrow0, nc, rs_r, rv[q]);
             else lean_res_load<48>(p, lane, mrow0, nc, rs_r, rv[q]);
         };
-        // residual rows of ALL passes -> registers, before the first store (see above)
+        // residual rows of ALL passes -> registers, before the first store (see above); already there for the small wave tiles
+        if constexpr (EARLY_RES && RES) {
+            static_assert(E_NPASS == NCG * NJB, "pass geometry");
+            if (early_res) {
 #pragma unroll
-        for (int q = 0; q < (RES ? NCG * NJB : 1); ++q) issue_res(q);
+                for (int q = 0; q < NCG * NJB; ++q)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) rv[q][it] = rv_early[q][it];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NCG * NJB; ++q) issue_res(q);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < (RES ? NCG * NJB : 1); ++q) issue_res(q);
+        }
         const bool swiglu = p.act == PCDM_ACT_SILU;
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;          // bias of this lane's 8 channels: re-read (LDS) once per column group
 #pragma unroll

@@ -1,0 +1,690 @@
+// The UNet forward as ONE C entry: pcdm_unet_forward(ctx, ...) (SURVEY.md §8b "fused unet_forward(ctx, ...)" + opaque ctx).
+//
+// Host code only -- a schedule of calls into the kernels of this library, the C++ twin of pcdms_amd/unet.py::_forward_nhwc /
+// prepare_conditioning (which follow /root/reference/src/models/stage2_inpaint_unet_2d_condition.py:579-825 and the diffusers 0.24.0
+// blocks of SURVEY.md Appendix A).  A host without Python builds a pcdm_unet from a topology description, registers the packed
+// weights by their diffusers module paths (pcdm_pack_* produce the layouts from fp32 host tensors), hands over ONE workspace, and runs
+// prepare_conditioning once per sampling call and forward once per denoise step; nothing is allocated inside, every launch goes to the
+// caller's stream, all scratch addresses are fixed by the plan (the whole step is capturable in a hipGraph).
+// The Python package keeps its own schedule (autotuning, fp8 attention, emulator tests); tests/test_unet_ctx.py holds the two to
+// bit-identical outputs.
+#include "pcdm_device.h"
+#include "../../include/pcdm.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace {
+struct PW {   // a packed weight as pcdm_gemm wants it
+    const void* w = nullptr;
+    const float* bias = nullptr;
+    const float* wsum = nullptr;   // row sums of LayerNorm-folded weights (pcdm_gemm_params.ln_wsum)
+    int N = 0, K = 0, Npad = 0, cin = 0;
+};
+struct Vec {
+    const float* v = nullptr;
+    int n = 0;
+};
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int> TileKey;   // ln, M, Npad, K, conv, stride, upsample, epilogue, two-source, residual, zero_rows
+
+struct Buf {
+    int64_t off = 0, bytes = 0;
+};
+}  // namespace
+
+struct pcdm_unet {
+    pcdm_unet_config cfg;
+    std::map<std::string, PW> w;
+    std::map<std::string, Vec> v;
+    std::map<TileKey, std::pair<int, int>> tiles;
+    // plan (valid for plan_key)
+    std::tuple<int, int, int, int> plan_key{0, 0, 0, 0};
+    std::map<std::string, Buf> bufs;
+    int64_t ws_bytes = 0;
+    int n0 = 0;   // leading batch entries with an all-zero context (set by prepare_conditioning)
+    std::string err;
+};
+
+namespace {
+constexpr int64_t kAlign = 256;
+constexpr int64_t kSplitKFloats = 1 << 24;   // split-K workspace (fp32), as pcdms_amd.ops._splitk_ws
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct Planner {
+    pcdm_unet* u;
+    int64_t off = 0;
+    void add(const std::string& name, int64_t bytes) {
+        auto it = u->bufs.find(name);
+        if (it != u->bufs.end()) {   // same name, larger use: grow in place only while it is the last buffer; otherwise keep the max up front
+            if (it->second.bytes >= bytes) return;
+        }
+        Buf b;
+        b.off = off;
+        b.bytes = round_up(bytes, kAlign);
+        off += b.bytes;
+        u->bufs[name] = b;
+    }
+};
+
+std::vector<std::tuple<std::string, int, int, int>> resnets(const pcdm_unet_config& c) {   // (prefix, cin, cout, level)
+    std::vector<std::tuple<std::string, int, int, int>> r;
+    const int n = c.n_levels, L = c.layers_per_block;
+    int out = c.block_out_channels[0];
+    for (int i = 0; i < n; ++i) {
+        const int cin = out;
+        out = c.block_out_channels[i];
+        for (int j = 0; j < L; ++j) r.emplace_back("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", j == 0 ? cin : out, out, i);
+    }
+    r.emplace_back("mid_block.resnets.0.", c.block_out_channels[n - 1], c.block_out_channels[n - 1], n - 1);
+    r.emplace_back("mid_block.resnets.1.", c.block_out_channels[n - 1], c.block_out_channels[n - 1], n - 1);
+    out = c.block_out_channels[n - 1];
+    for (int i = 0; i < n; ++i) {
+        const int prev = out;
+        out = c.block_out_channels[n - 1 - i];
+        const int inc = c.block_out_channels[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+        for (int j = 0; j < L + 1; ++j) {
+            const int skip = j == L ? inc : out, rin = j == 0 ? prev : out;
+            r.emplace_back("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", rin + skip, out, n - 1 - i);
+        }
+    }
+    return r;
+}
+
+// time-embedding column offset of every resnet inside the concatenated time_emb_proj (registration order == resnets())
+std::map<std::string, int> temb_offsets(const pcdm_unet_config& c, int* total) {
+    std::map<std::string, int> m;
+    int off = 0;
+    for (auto& r : resnets(c)) {
+        m[std::get<0>(r)] = off;
+        off += std::get<2>(r);
+    }
+    *total = off;
+    return m;
+}
+
+struct Run {   // one forward / conditioning pass: helpers around the C-ABI calls
+    pcdm_unet* u;
+    char* ws;
+    pcdm_stream_t st;
+    int rc = 0;
+
+    template <typename T = void>
+    T* buf(const std::string& name) {
+        auto it = u->bufs.find(name);
+        if (it == u->bufs.end()) {
+            u->err = "no buffer " + name;
+            rc = -1;
+            return nullptr;
+        }
+        return (T*)(ws + it->second.off);
+    }
+    const PW* pw(const std::string& name) {
+        auto it = u->w.find(name);
+        if (it == u->w.end()) {
+            u->err = "weight not registered: " + name;
+            rc = -1;
+            return nullptr;
+        }
+        return &it->second;
+    }
+    const float* vec(const std::string& name) {
+        auto it = u->v.find(name);
+        if (it == u->v.end()) {
+            u->err = "vector not registered: " + name;
+            rc = -1;
+            return nullptr;
+        }
+        return it->second.v;
+    }
+    void chk(int r, const char* what) {
+        if (r != 0 && rc == 0) {
+            rc = r;
+            u->err = std::string(what) + " failed";
+        }
+    }
+
+    struct G {   // optional arguments of gemm()
+        const void* a2 = nullptr;
+        int64_t lda2 = 0;
+        const float* rowvec = nullptr;
+        int64_t ldrv = 0;
+        int rows_per_batch = 0;
+        const void* residual = nullptr;
+        int64_t ldr = 0;
+        int res_mod = 0;
+        int epilogue = PCDM_EPI_STORE;
+        void* out2 = nullptr;
+        int64_t ldo2 = 0;
+        int vt_col0 = 0;
+        int conv = 0, B = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, stride = 1, upsample = 0;
+        int zero_rows = 0;
+        int64_t ldo = 0;   // 0: N (GEGLU / NCHW: N)
+        const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles only)
+        float ln_eps = 0.f;
+    };
+    // out = epilogue(A W^T): the parameter block pcdms_amd.ops.gemm builds, the tile from the registered table (0 = library heuristic)
+    void gemm(const void* a, int64_t lda, int M, const PW* w, void* out, const G& g) {
+        if (rc || !w) return;
+        pcdm_gemm_params p;
+        memset(&p, 0, sizeof(p));
+        p.a = a;
+        p.lda = lda;
+        p.c1 = g.a2 ? (int)lda : w->K;
+        p.a2 = g.a2;
+        p.lda2 = g.lda2;
+        p.conv = g.conv;
+        if (g.conv) {
+            p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi; p.Ho = g.Ho; p.Wo = g.Wo;
+            p.stride = g.stride; p.upsample = g.upsample; p.cin = w->cin;
+        }
+        p.w = w->w;
+        p.M = M; p.N = w->N; p.K = w->K; p.Npad = w->Npad;
+        p.bias = w->bias;
+        p.rowvec = g.rowvec;
+        p.ldrv = g.ldrv;
+        p.rows_per_batch = g.rows_per_batch ? g.rows_per_batch : M;
+        p.residual = g.residual;
+        p.ldr = g.residual ? (g.ldr ? g.ldr : w->N) : 0;
+        p.res_mod = g.res_mod;
+        p.epilogue = g.epilogue;
+        p.vt_col0 = g.vt_col0;
+        p.out = out;
+        p.ldo = g.ldo ? g.ldo : w->N;
+        p.out2 = g.out2;
+        p.ldo2 = g.ldo2;
+        p.zero_rows = g.zero_rows;
+        const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : 0};
+        auto it = u->tiles.find(key);
+        if (it != u->tiles.end()) {
+            p.tile = it->second.first;
+            if (it->second.second > 1) {
+                p.split_k = it->second.second;
+                p.ws = buf<float>("splitk");
+                p.ws_floats = kSplitKFloats;
+                if ((int64_t)p.split_k * M * w->Npad > kSplitKFloats) { p.split_k = 0; p.tile = 0; p.ws = nullptr; p.ws_floats = 0; }
+            }
+        }
+        chk(pcdm_gemm(&p, st), "pcdm_gemm");
+    }
+    // LayerNorm -> GEMM: the folded form on the A-in-registers kernel when the table says so, two launches otherwise
+    void gemm_ln(const void* a, int64_t lda, int M, const PW* w, const PW* w_ln, const float* gamma, const float* beta, float eps, void* ln_buf,
+                 void* out, G g) {
+        if (rc || !w) return;
+        if (w_ln && w_ln->wsum) {
+            auto it = u->tiles.find(TileKey{1, M, w->Npad, w->K, 0, 0, 0, g.epilogue, 0, 0, 0});
+            if (it != u->tiles.end() && it->second.first >= 31) {
+                pcdm_gemm_params p;
+                memset(&p, 0, sizeof(p));
+                p.a = a; p.lda = lda; p.c1 = w->K;
+                p.w = w_ln->w; p.M = M; p.N = w_ln->N; p.K = w_ln->K; p.Npad = w_ln->Npad;
+                p.bias = w_ln->bias;
+                p.rows_per_batch = g.rows_per_batch ? g.rows_per_batch : M;
+                p.epilogue = g.epilogue; p.vt_col0 = g.vt_col0;
+                p.out = out; p.ldo = g.ldo ? g.ldo : w->N;
+                p.out2 = g.out2; p.ldo2 = g.ldo2;
+                p.ln_wsum = w_ln->wsum; p.ln_eps = eps;
+                p.tile = it->second.first;
+                chk(pcdm_gemm(&p, st), "pcdm_gemm (LayerNorm folded)");
+                return;
+            }
+        }
+        chk(pcdm_layernorm(a, ln_buf, M, w->K, eps, gamma, beta, st), "pcdm_layernorm");
+        gemm(ln_buf, w->K, M, w, out, g);
+    }
+    void groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, float eps, const float* gamma, const float* beta, int silu, void* y) {
+        if (rc) return;
+        chk(pcdm_groupnorm(x1, C1, x2, C2, B, HW, u->cfg.norm_groups, eps, gamma, beta, silu, y, buf<float>("gnws"), st), "pcdm_groupnorm");
+    }
+};
+
+int64_t lp8(int64_t v) { return (v + 7) / 8 * 8; }
+
+bool has_cross(const pcdm_unet_config& c, int level) { return c.cross_attn[level] != 0; }
+
+// transformer prefixes in registration / schedule order with (channels, heads)
+std::vector<std::tuple<std::string, int, int>> transformers(const pcdm_unet_config& c) {
+    std::vector<std::tuple<std::string, int, int>> t;
+    const int n = c.n_levels, L = c.layers_per_block;
+    for (int i = 0; i < n; ++i)
+        if (has_cross(c, i))
+            for (int j = 0; j < L; ++j) t.emplace_back("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", c.block_out_channels[i], c.heads[i]);
+    t.emplace_back("mid_block.attentions.0.", c.block_out_channels[n - 1], c.heads[n - 1]);
+    for (int i = 0; i < n; ++i)
+        if (has_cross(c, n - 1 - i))
+            for (int j = 0; j < L + 1; ++j)
+                t.emplace_back("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", c.block_out_channels[n - 1 - i], c.heads[n - 1 - i]);
+    return t;
+}
+
+int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
+    const auto key = std::make_tuple(B, h, w, L);
+    if (u->plan_key == key && !u->bufs.empty()) return 0;
+    const pcdm_unet_config& c = u->cfg;
+    u->bufs.clear();
+    Planner P{u};
+    const int n = c.n_levels;
+    const int C0 = c.block_out_channels[0], temb_dim = 4 * C0;
+    int Cmax = 0;
+    for (int i = 0; i < n; ++i) Cmax = c.block_out_channels[i] > Cmax ? c.block_out_channels[i] : Cmax;
+    const int64_t HW = (int64_t)h * w, M0 = B * HW;
+    int temb_n = 0;
+    temb_offsets(c, &temb_n);
+    // ---- conditioning (step-invariant)
+    P.add("gnws", pcdm_groupnorm_ws_floats(B, 4096) * 4);
+    P.add("splitk", kSplitKFloats * 4);
+    P.add("cls1", (int64_t)B * temb_dim * 4);
+    P.add("cls2", (int64_t)B * temb_dim * 4);
+    P.add("pose", M0 * C0 * 2);
+    P.add("ctx", (int64_t)B * L * c.cross_attention_dim * 2);
+    for (auto& t : transformers(c)) {
+        const int cc = std::get<1>(t);
+        P.add("k2:" + std::get<0>(t), (int64_t)B * L * cc * 2);
+        P.add("vt2:" + std::get<0>(t), (int64_t)B * cc * lp8(L) * 2);
+    }
+    // ---- per step
+    P.add("t_emb", (int64_t)B * C0 * 4);
+    P.add("e1", (int64_t)B * temb_dim * 4);
+    P.add("emb", (int64_t)B * temb_dim * 4);
+    P.add("emb_bf", (int64_t)B * temb_dim * 2);
+    P.add("temb", (int64_t)B * temb_n * 4);
+    // activations: sized for level 0 (the largest at every name); channel maxima from the topology
+    int cin_max = 0;
+    for (auto& r : resnets(c)) cin_max = std::get<1>(r) > cin_max ? std::get<1>(r) : cin_max;
+    // rows x channels never exceed M0 x max(channels at that level): a safe bound is max over levels of M_l * C_l-ish; use per-level maxima
+    int64_t act = 0, act_gn = 0, act_ff = 0, act_qk = 0, act_vt = 0;
+    {
+        int hh = h, ww = w;
+        for (int i = 0; i < n; ++i) {
+            const int64_t M = (int64_t)B * hh * ww;
+            const int ci = c.block_out_channels[i];
+            int cin_l = ci;
+            for (auto& r : resnets(c))
+                if (std::get<3>(r) == i) cin_l = std::get<1>(r) > cin_l ? std::get<1>(r) : cin_l;
+            // the upsampling conv of up-block (n-1-i-1 .. ) writes level i rows with the channels of level i+1
+            const int cup = i + 1 < n ? c.block_out_channels[i + 1] : ci;
+            act = std::max(act, M * std::max(ci, cup) * 2);
+            act_gn = std::max(act_gn, M * cin_l * 2);
+            act_ff = std::max(act_ff, M * 4 * ci * 2);
+            act_qk = std::max(act_qk, M * 2 * ci * 2);
+            act_vt = std::max(act_vt, (int64_t)B * ci * lp8((int64_t)hh * ww) * 2);
+            if (i != n - 1) { hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1; }
+        }
+    }
+    for (const char* nm : {"r", "rb", "u", "ub", "r2", "c1", "sc", "t0", "t1", "ln", "q2", "at", "us"}) P.add(nm, act);
+    P.add("gn", act_gn);
+    P.add("ff", act_ff);
+    P.add("qk", act_qk);
+    P.add("vt", act_vt);
+    {   // skip tensors: one buffer per skip, exact sizes
+        int hh = h, ww = w;
+        P.add("skip0", M0 * C0 * 2);
+        for (int i = 0; i < n; ++i) {
+            const int64_t M = (int64_t)B * hh * ww;
+            for (int j = 0; j < c.layers_per_block; ++j) P.add("d" + std::to_string(i) + "." + std::to_string(j), M * c.block_out_channels[i] * 2);
+            if (i != n - 1) {
+                hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1;
+                P.add("ds" + std::to_string(i), (int64_t)B * hh * ww * c.block_out_channels[i] * 2);
+            }
+        }
+    }
+    u->ws_bytes = P.off;
+    u->plan_key = key;
+    return 0;
+}
+}  // namespace
+
+extern "C" pcdm_unet* pcdm_unet_create(const pcdm_unet_config* cfg) {
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->layers_per_block < 1) return nullptr;
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->block_out_channels[i] % 64 || cfg->heads[i] <= 0 || cfg->block_out_channels[i] / cfg->heads[i] != 64) return nullptr;
+    pcdm_unet* u = new pcdm_unet();
+    u->cfg = *cfg;
+    return u;
+}
+
+extern "C" void pcdm_unet_destroy(pcdm_unet* u) { delete u; }
+
+extern "C" const char* pcdm_unet_last_error(const pcdm_unet* u) { return u ? u->err.c_str() : "null context"; }
+
+extern "C" int pcdm_unet_set_weight(pcdm_unet* u, const char* name, const void* w, const float* bias, const float* wsum, int N, int K, int Npad,
+                                    int cin) {
+    if (!u || !name || !w || N <= 0 || K <= 0 || Npad < N) return -1;
+    PW p;
+    p.w = w; p.bias = bias; p.wsum = wsum; p.N = N; p.K = K; p.Npad = Npad; p.cin = cin;
+    u->w[name] = p;
+    u->bufs.clear();
+    return 0;
+}
+
+extern "C" int pcdm_unet_set_vector(pcdm_unet* u, const char* name, const float* v, int n) {
+    if (!u || !name || !v || n <= 0) return -1;
+    u->v[name] = Vec{v, n};
+    return 0;
+}
+
+extern "C" int pcdm_unet_set_tile(pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source,
+                                  int residual, int zero_rows, int tile, int split_k) {
+    if (!u || tile < 0) return -1;
+    u->tiles[TileKey{ln, M, Npad, K, conv, stride, upsample, epilogue, two_source, residual, zero_rows}] = {tile, split_k};
+    return 0;
+}
+
+extern "C" int64_t pcdm_unet_workspace_bytes(pcdm_unet* u, int B, int h, int w, int L) {
+    if (!u || B <= 0 || h <= 0 || w <= 0 || L <= 0) return -1;
+    if (make_plan(u, B, h, w, L)) return -1;
+    return u->ws_bytes;
+}
+
+// Zero the regions that must start at zero (GroupNorm arrival counters, the padding columns of the V^T buffers); once per workspace.
+extern "C" int pcdm_unet_workspace_init(pcdm_unet* u, int B, int h, int w, int L, void* workspace, pcdm_stream_t s) {
+    if (!u || !workspace || make_plan(u, B, h, w, L)) return -1;
+#ifdef PCDM_EMU
+    memset(workspace, 0, (size_t)u->ws_bytes);
+    (void)s;
+    return 0;
+#else
+    return hipMemsetAsync(workspace, 0, (size_t)u->ws_bytes, (hipStream_t)s) == hipSuccess ? 0 : -1000;
+#endif
+}
+
+// Step-invariant part of a sampling call (pcdms_amd/unet.py::prepare_conditioning; ref :688-708, :742 and the 16 attn2.to_k / to_v):
+// class embedding, NHWC bf16 pose feature, cross-attention K / V^T of the context.  ehs fp32 [B, L, ctx] (device); class_labels fp32
+// [B, class_embed_dim] or NULL; pose fp32 NCHW [pose_b, C0, h, w] (pose_b = 1 or B) or NULL; the first zero_ctx_batches batch entries of
+// ehs are all-zero (their K / V are not projected, their cross-attention is not run).
+extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w, int L, const float* ehs, const float* class_labels, const float* pose,
+                                              int pose_b, int zero_ctx_batches, void* workspace, pcdm_stream_t s) {
+    if (!u || !ehs || !workspace || make_plan(u, B, h, w, L)) return -1;
+    const pcdm_unet_config& c = u->cfg;
+    Run R{u, (char*)workspace, s};
+    const int temb_dim = 4 * c.block_out_channels[0];
+    int n0 = zero_ctx_batches;
+    if (n0 < 0 || n0 > B) return -1;
+    if (n0 == B) n0 = B > 1 ? B - 1 : 0;
+    u->n0 = n0;
+    if (c.class_embed) {
+        if (!class_labels) return -1;
+        const PW *c1 = R.pw("class_embedding.linear_1"), *c2 = R.pw("class_embedding.linear_2");
+        if (R.rc) return R.rc;
+        R.chk(pcdm_small_linear(class_labels, c1->w, c1->bias, nullptr, R.buf<float>("cls1"), B, c1->K, c1->N, 0, 1, s), "pcdm_small_linear");
+        R.chk(pcdm_small_linear(R.buf<float>("cls1"), c2->w, c2->bias, nullptr, R.buf<float>("cls2"), B, c2->K, c2->N, 0, 0, s), "pcdm_small_linear");
+    }
+    if (pose) {
+        if (pose_b != 1 && pose_b != B) return -1;
+        R.chk(pcdm_nchw_f32_to_nhwc_bf16(pose, R.buf("pose"), pose_b, c.block_out_channels[0], c.block_out_channels[0], h * w, s), "nchw_to_nhwc");
+    }
+    (void)temb_dim;
+    const int Bc = B - n0;
+    R.chk(pcdm_f32_to_bf16(ehs + (int64_t)n0 * L * c.cross_attention_dim, R.buf("ctx"), (int64_t)Bc * L * c.cross_attention_dim, s), "f32_to_bf16");
+    for (auto& t : transformers(c)) {
+        const std::string& p = std::get<0>(t);
+        const int cc = std::get<1>(t);
+        Run::G g;
+        g.rows_per_batch = L;
+        g.epilogue = PCDM_EPI_SPLIT_VT;
+        g.out2 = R.buf("vt2:" + p);
+        g.ldo2 = lp8(L);
+        g.vt_col0 = cc;
+        g.ldo = cc;
+        R.gemm(R.buf("ctx"), c.cross_attention_dim, Bc * L, R.pw(p + "kv2"), R.buf("k2:" + p), g);
+    }
+    return R.rc;
+}
+
+// One UNet forward (pcdms_amd/unet.py::_forward_nhwc): x_in NHWC bf16 [B, h, w, conv_in.cin]; the timestep is t_dev[step_dev ? *step_dev : 0]
+// (device memory: graph-replayable); eps_out fp32 NCHW [B, out_channels, h, w].  prepare_conditioning must have run on this workspace.
+extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* t_dev, const int32_t* step_dev, int B, int h, int w, int L,
+                                 int pose_b, void* workspace, float* eps_out, pcdm_stream_t s) {
+    if (!u || !x_in || !t_dev || !workspace || !eps_out || make_plan(u, B, h, w, L)) return -1;
+    const pcdm_unet_config& c = u->cfg;
+    Run R{u, (char*)workspace, s};
+    const int n = c.n_levels, Lb = c.layers_per_block, G = c.norm_groups;
+    const int C0 = c.block_out_channels[0], temb_dim = 4 * C0;
+    const float eps = c.norm_eps;
+    int temb_n = 0;
+    const std::map<std::string, int> toff = temb_offsets(c, &temb_n);
+    const int n0 = u->n0;
+
+    // ---- 1. time / class embedding (ref :661-708)
+    R.chk(pcdm_timestep_embedding(t_dev, step_dev, R.buf<float>("t_emb"), B, C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding");
+    {
+        const PW *t1 = R.pw("time_embedding.linear_1"), *t2 = R.pw("time_embedding.linear_2");
+        if (R.rc) return R.rc;
+        R.chk(pcdm_small_linear(R.buf<float>("t_emb"), t1->w, t1->bias, nullptr, R.buf<float>("e1"), B, t1->K, t1->N, 0, 1, s), "pcdm_small_linear");
+        // emb = time_emb + class_emb is only ever consumed as silu(emb) (ResnetBlock2D): applied here, once
+        R.chk(pcdm_small_linear(R.buf<float>("e1"), t2->w, t2->bias, c.class_embed ? R.buf<float>("cls2") : nullptr, R.buf<float>("emb"), B, t2->K, t2->N, 0,
+                                c.class_embed ? 2 : 1, s), "pcdm_small_linear");
+        R.chk(pcdm_f32_to_bf16(R.buf<float>("emb"), R.buf("emb_bf"), (int64_t)B * temb_dim, s), "f32_to_bf16");
+        Run::G g;
+        g.rows_per_batch = 1;
+        g.epilogue = PCDM_EPI_NCHW_F32;
+        R.gemm(R.buf("emb_bf"), temb_dim, B, R.pw("time_emb_proj"), R.buf("temb"), g);   // every ResnetBlock2D.time_emb_proj in one launch
+    }
+    const float* temb = R.buf<float>("temb");
+
+    auto resnet = [&](const std::string& p, const void* x1, int C1, const void* x2, int C2, int HW_, int hh, int ww, const std::string& out_name) -> void* {
+        const PW *cv1 = R.pw(p + "conv1"), *cv2 = R.pw(p + "conv2");
+        if (R.rc) return nullptr;
+        const int cin = C1 + C2, cout = cv1->N, M = B * HW_;
+        R.groupnorm(x1, C1, x2, C2, B, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"), 1, R.buf("gn"));
+        Run::G g;
+        g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = hh; g.Wo = ww;
+        g.rowvec = temb + toff.at(p); g.ldrv = temb_n; g.rows_per_batch = HW_;
+        R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
+        R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
+        const void* res = x1;
+        if (u->w.count(p + "conv_shortcut")) {
+            Run::G gs;
+            gs.a2 = x2; gs.lda2 = C2;
+            R.gemm(x1, C1, M, R.pw(p + "conv_shortcut"), R.buf("sc"), gs);
+            res = R.buf("sc");
+        }
+        Run::G g2;
+        g2.conv = 1; g2.B = B; g2.Hi = hh; g2.Wi = ww; g2.Ho = hh; g2.Wo = ww;
+        g2.residual = res; g2.ldr = cout; g2.res_mod = M;
+        void* out = R.buf(out_name);
+        R.gemm(R.buf("gn"), cout, M, cv2, out, g2);
+        return out;
+    };
+
+    auto transformer = [&](const std::string& p, const void* x, int cc, int H, int HW_, const std::string& out_name) -> void* {
+        const int M = B * HW_;
+        const std::string b = p + "transformer_blocks.0.";
+        R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"));
+        Run::G g0;
+        R.gemm(R.buf("gn"), cc, M, R.pw(p + "proj_in"), R.buf("t0"), g0);
+        // self-attention
+        {
+            Run::G g;
+            g.rows_per_batch = HW_; g.epilogue = PCDM_EPI_SPLIT_VT; g.out2 = R.buf("vt"); g.ldo2 = lp8(HW_); g.vt_col0 = 2 * cc; g.ldo = 2 * cc;
+            const PW* wl = u->w.count(p + "qkv_ln") ? &u->w[p + "qkv_ln"] : nullptr;
+            R.gemm_ln(R.buf("t0"), cc, M, R.pw(p + "qkv"), wl, R.vec(b + "norm1.weight"), R.vec(b + "norm1.bias"), 1e-5f, R.buf("ln"), R.buf("qk"), g);
+        }
+        u16* qk = R.buf<u16>("qk");
+        if (R.rc) return nullptr;
+        R.chk(pcdm_flash_attn(qk, 2 * cc, qk + cc, 2 * cc, R.buf("vt"), lp8(HW_), R.buf("at"), cc, B, H, HW_, HW_, 0.125f, s), "pcdm_flash_attn");
+        {
+            Run::G g;
+            g.residual = R.buf("t0"); g.ldr = cc; g.res_mod = M;
+            R.gemm(R.buf("at"), cc, M, R.pw(p + "o1"), R.buf("t1"), g);
+        }
+        // cross-attention over the context tokens; the first n0 batch entries have an all-zero context: attn2(x) == to_out.0.bias there
+        const int64_t r0 = (int64_t)n0 * HW_;
+        u16 *t1 = R.buf<u16>("t1"), *ln = R.buf<u16>("ln"), *q2 = R.buf<u16>("q2"), *at = R.buf<u16>("at");
+        {
+            Run::G g;
+            const PW* wl = u->w.count(p + "q2_ln") ? &u->w[p + "q2_ln"] : nullptr;
+            R.gemm_ln(t1 + r0 * cc, cc, M - (int)r0, R.pw(p + "q2"), wl, R.vec(b + "norm2.weight"), R.vec(b + "norm2.bias"), 1e-5f, ln + r0 * cc, q2 + r0 * cc, g);
+        }
+        if (R.rc) return nullptr;
+        R.chk(pcdm_flash_attn(q2 + r0 * cc, cc, R.buf("k2:" + p), cc, R.buf("vt2:" + p), lp8(L), at + r0 * cc, cc, B - n0, H, HW_, L, 0.125f, s), "pcdm_flash_attn");
+        {
+            Run::G g;
+            g.residual = t1; g.ldr = cc; g.res_mod = M; g.zero_rows = (int)r0;
+            R.gemm(at, cc, M, R.pw(p + "o2"), R.buf("t0"), g);
+        }
+        // GEGLU feed-forward
+        {
+            Run::G g;
+            g.epilogue = PCDM_EPI_GEGLU; g.ldo = 4 * cc;
+            const PW* wl = u->w.count(p + "ff1_ln") ? &u->w[p + "ff1_ln"] : nullptr;
+            R.gemm_ln(R.buf("t0"), cc, M, R.pw(p + "ff1"), wl, R.vec(b + "norm3.weight"), R.vec(b + "norm3.bias"), 1e-5f, R.buf("ln"), R.buf("ff"), g);
+        }
+        {
+            Run::G g;
+            g.residual = R.buf("t0"); g.ldr = cc; g.res_mod = M;
+            R.gemm(R.buf("ff"), 4 * cc, M, R.pw(p + "ff2"), R.buf("t1"), g);
+        }
+        Run::G g;
+        g.residual = x; g.ldr = cc; g.res_mod = M;
+        void* out = R.buf(out_name);
+        R.gemm(R.buf("t1"), cc, M, R.pw(p + "proj_out"), out, g);
+        return out;
+    };
+
+    // ---- 2. conv_in + pose (ref :742)
+    const int HW = h * w;
+    struct Skip { const void* p; int hh, ww, ch; };
+    std::vector<Skip> skips;
+    const void* x;
+    {
+        Run::G g;
+        g.conv = 1; g.B = B; g.Hi = h; g.Wi = w; g.Ho = h; g.Wo = w;
+        if (pose_b > 0) { g.residual = R.buf("pose"); g.ldr = C0; g.res_mod = pose_b * HW; }
+        R.gemm(x_in, 0, B * HW, R.pw("conv_in"), R.buf("skip0"), g);
+        x = R.buf("skip0");
+    }
+    skips.push_back({x, h, w, C0});
+    // ---- 3. down (ref :746-761)
+    int hh = h, ww = w;
+    for (int i = 0; i < n && !R.rc; ++i) {
+        const int ci = c.block_out_channels[i];
+        int cprev = i == 0 ? C0 : c.block_out_channels[i - 1];
+        for (int j = 0; j < Lb; ++j) {
+            const std::string nm = "d" + std::to_string(i) + "." + std::to_string(j), rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".";
+            if (has_cross(c, i)) {
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r");
+                x = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, ci, c.heads[i], hh * ww, nm);
+            } else {
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm);
+            }
+            skips.push_back({x, hh, ww, ci});
+        }
+        if (i != n - 1) {
+            const int ho = (hh - 1) / 2 + 1, wo = (ww - 1) / 2 + 1;
+            Run::G g;
+            g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = ho; g.Wo = wo; g.stride = 2;
+            void* o = R.buf("ds" + std::to_string(i));
+            R.gemm(x, 0, B * ho * wo, R.pw("down_blocks." + std::to_string(i) + ".downsamplers.0.conv"), o, g);
+            x = o;
+            hh = ho; ww = wo;
+            skips.push_back({x, hh, ww, ci});
+        }
+    }
+    // ---- 4. mid (ref :775-783)
+    const int cm = c.block_out_channels[n - 1];
+    x = resnet("mid_block.resnets.0.", x, cm, nullptr, 0, hh * ww, hh, ww, "r");
+    x = transformer("mid_block.attentions.0.", x, cm, c.heads[n - 1], hh * ww, "r2");
+    x = resnet("mid_block.resnets.1.", x, cm, nullptr, 0, hh * ww, hh, ww, "r");
+    // ---- 5. up (ref :789-814)
+    int cx = cm;
+    for (int i = 0; i < n && !R.rc; ++i) {
+        const int co = c.block_out_channels[n - 1 - i];
+        for (int j = 0; j < Lb + 1; ++j) {
+            const Skip sk = skips.back();
+            skips.pop_back();
+            if (sk.hh != hh || sk.ww != ww) { u->err = "skip size mismatch"; return -1; }
+            x = resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", x, cx, sk.p, sk.ch, hh * ww, hh, ww, (j + i) % 2 ? "r" : "rb");
+            cx = co;
+            if (has_cross(c, n - 1 - i))
+                x = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, co, c.heads[n - 1 - i], hh * ww, j % 2 ? "u" : "ub");
+        }
+        if (i != n - 1) {
+            const int ho = skips.back().hh, wo = skips.back().ww;   // = (2 hh, 2 ww) unless a down conv rounded an odd size up
+            Run::G g;
+            g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = ho; g.Wo = wo; g.upsample = 1;
+            R.gemm(x, 0, B * ho * wo, R.pw("up_blocks." + std::to_string(i) + ".upsamplers.0.conv"), R.buf("us"), g);
+            x = R.buf("us");
+            hh = ho; ww = wo;
+        }
+    }
+    // ---- 6. post-process (ref :817-820)
+    R.groupnorm(x, C0, nullptr, 0, B, HW, eps, R.vec("conv_norm_out.weight"), R.vec("conv_norm_out.bias"), 1, R.buf("gn"));
+    {
+        Run::G g;
+        g.conv = 1; g.B = B; g.Hi = h; g.Wi = w; g.Ho = h; g.Wo = w; g.rows_per_batch = HW; g.epilogue = PCDM_EPI_NCHW_F32;
+        R.gemm(R.buf("gn"), 0, B * HW, R.pw("conv_out"), eps_out, g);
+    }
+    return R.rc;
+}
+
+// ---- weight packing for hosts without pcdms_amd.ops.pack_* (plain host loops; the caller uploads the result) ---------------------------
+namespace {
+inline uint16_t host_f2bf(float f) {   // round-to-nearest-even, NaN preserved (the conversion torch's .to(bfloat16) performs)
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40);
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+}  // namespace
+
+// nn.Linear / 1x1-conv weight fp32 [N, K] -> bf16 [Npad, K] (rows >= N zero), Npad = N rounded up to pad_to (64); bias -> fp32 [Npad].
+// Returns Npad; out_w / out_bias may be NULL to query the size.
+extern "C" int pcdm_pack_linear(const float* w, const float* bias, int N, int K, int pad_to, uint16_t* out_w, float* out_bias) {
+    if (N <= 0 || K <= 0 || K % 64 || pad_to <= 0) return -1;
+    const int Npad = (N + pad_to - 1) / pad_to * pad_to;
+    if (out_w) {
+        if (!w) return -1;
+        for (int64_t n = 0; n < Npad; ++n)
+            for (int64_t k = 0; k < K; ++k) out_w[n * K + k] = n < N ? host_f2bf(w[n * K + k]) : 0;
+    }
+    if (out_bias)
+        for (int n = 0; n < Npad; ++n) out_bias[n] = (bias && n < N) ? bias[n] : 0.f;
+    return Npad;
+}
+
+// Conv2d weight fp32 [N, Cin, 3, 3] -> bf16 [Npad, 9 * Cp], k = (ky * 3 + kx) * Cp + c, Cp = Cin rounded up to 64.  Returns Npad; *K_out = 9 Cp,
+// *cin_out = Cp.
+extern "C" int pcdm_pack_conv3x3(const float* w, const float* bias, int N, int Cin, int pad_to, uint16_t* out_w, float* out_bias, int* K_out,
+                                 int* cin_out) {
+    if (N <= 0 || Cin <= 0 || pad_to <= 0) return -1;
+    const int Cp = (Cin + 63) / 64 * 64, K = 9 * Cp;
+    const int Npad = (N + pad_to - 1) / pad_to * pad_to;
+    if (K_out) *K_out = K;
+    if (cin_out) *cin_out = Cp;
+    if (out_w) {
+        if (!w) return -1;
+        memset(out_w, 0, (size_t)Npad * K * sizeof(uint16_t));
+        for (int64_t n = 0; n < N; ++n)
+            for (int c = 0; c < Cin; ++c)
+                for (int t = 0; t < 9; ++t) out_w[n * K + t * Cp + c] = host_f2bf(w[(n * Cin + c) * 9 + t]);
+    }
+    if (out_bias)
+        for (int n = 0; n < Npad; ++n) out_bias[n] = (bias && n < N) ? bias[n] : 0.f;
+    return Npad;
+}
+
+// GEGLU projection fp32 [2 D, K] (rows [h | gate]) + bias [2 D] -> bf16 [2 Dp, K] with rows interleaved per 64 as [32 h | 32 gate]
+// (Dp = D rounded up to 64), bias likewise.  Returns Npad = 2 Dp; the GEMM's N is D.
+extern "C" int pcdm_pack_geglu(const float* w, const float* bias, int D, int K, uint16_t* out_w, float* out_bias) {
+    if (D <= 0 || K <= 0 || K % 64) return -1;
+    const int Dp = (D + 63) / 64 * 64;
+    for (int64_t r = 0; r < 2 * Dp && (out_w || out_bias); ++r) {
+        const int blk = (int)(r / 64), in = (int)(r % 64);
+        const int d = blk * 32 + (in & 31);          // output channel
+        const bool gate = in >= 32;
+        const int64_t src = gate ? (int64_t)D + d : d;
+        if (out_w) {
+            if (!w) return -1;
+            for (int64_t k = 0; k < K; ++k) out_w[r * K + k] = d < D ? host_f2bf(w[src * K + k]) : 0;
+        }
+        if (out_bias) out_bias[r] = (bias && d < D) ? bias[src] : 0.f;
+    }
+    return 2 * Dp;
+}

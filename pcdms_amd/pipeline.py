@@ -66,11 +66,15 @@ class Stage2_InpaintDiffusionPipeline:
     #: only the 257 projected source-image tokens as context
     use_prior_embed = True
 
-    def __init__(self, unet: Stage2_InapintUNet2DConditionModel, scheduler, vae=None):
+    def __init__(self, unet: Stage2_InapintUNet2DConditionModel, scheduler, vae=None, c_schedule: bool = False):
         self.unet = unet
         self.scheduler = scheduler
         self.vae = vae
         self.vae_scale_factor = 8
+        #: run the UNet of the fused step through the single C entry ``pcdm_unet_forward`` (include/pcdm.h; pcdms_amd/unet_ctx.py)
+        #: instead of the Python schedule of ctypes calls: bit-identical results, one call per step
+        self.c_schedule = c_schedule
+        self._ctx = None
         self._graph = None
         self._graph_key = None
         self._st = {}
@@ -272,7 +276,10 @@ class Stage2_InpaintDiffusionPipeline:
         unet = self.unet
         B, h, w = st["B"], st["h"], st["w"]
         x_in = ops.assemble_input(st["lat"], st["rep"], st["mask"], st["masked"], st["x_in"])
-        eps = unet._forward_nhwc(x_in, B, h, w, st["timesteps"], st["cond"], step_dev=st["step"])
+        if st.get("ctx") is not None:
+            eps = st["ctx"].forward(x_in, st["timesteps"], st["step"], B, h, w, st["pose_b"], out=st["eps_c"])
+        else:
+            eps = unet._forward_nhwc(x_in, B, h, w, st["timesteps"], st["cond"], step_dev=st["step"])
         cfg, g, e = st["rep"] == 2, st["g"], eps
         if st["gr"] > 0.0:   # CFG -> rescale_noise_cfg (ref :510-516) -> scheduler update
             n = eps.shape[0] // 2
@@ -326,6 +333,23 @@ class Stage2_InpaintDiffusionPipeline:
             st["mask"].copy_(mask)
         st["masked"].copy_(masked)
         st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
+        st["ctx"] = None
+        if self.c_schedule:
+            from .unet_ctx import UNetContext
+            if self._ctx is None or self._ctx._pack_gen != unet._pack_gen or self._ctx.unet is not unet:
+                self._ctx = UNetContext(unet)
+                self._graph = None
+            if self._graph is None and dev.type == "cuda":   # one Python-schedule step first: it tunes every GEMM shape of this batch size
+                lat0 = lat.clone()
+                self._step_eager(st)
+                st["lat"].copy_(lat0)
+                st["step"].zero_()
+                self._zero_history(st)
+                self._ctx.sync_tiles()
+            st["pose_b"] = self._ctx.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
+            st["eps_c"] = st.get("eps_c") if st.get("eps_c") is not None and st["eps_c"].shape[0] == B else \
+                torch.empty(B, unet.config.out_channels, h, w, dtype=torch.float32, device=dev)
+            st["ctx"] = self._ctx
         st["timesteps"].copy_(timesteps.to(dev))
         st["coef"].copy_(self.scheduler.coefficient_table(device=dev) if unipc else self.scheduler.coefficient_table(eta, device=dev))
         st["g"] = g

@@ -15,7 +15,7 @@ ROOT = HERE.parent.parent
 CSRC = ROOT / "pcdms_amd" / "csrc"
 OUT = HERE / "_build"
 LIB = OUT / "libpcdm_emu.so"
-SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip", "unet_ctx.hip"]
 
 
 def _cxx() -> str:

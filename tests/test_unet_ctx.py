@@ -1,0 +1,134 @@
+"""pcdm_unet_forward(ctx, ...): the C-side schedule of the UNet (include/pcdm.h) against the Python schedule of
+pcdms_amd/unet.py -- the same kernels on the same packed weights with the same tile choices, so the two must agree BIT FOR BIT -- and,
+through it, against the oracle (tests/test_unet.py's tolerance)."""
+from __future__ import annotations
+
+import pytest
+import torch
+
+from oracle.unet import UNetConfig, synth_state_dict, unet_forward
+from pcdms_amd import ops
+from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel, UNet2DConditionModel
+from pcdms_amd.unet_ctx import UNetContext
+from tests.test_unet import _kwargs
+
+
+def _run_both(backend, cfg, B, h, w, L, n0, cls=Stage2_InapintUNet2DConditionModel, pose=True):
+    dev = backend.device
+    sd = synth_state_dict(cfg, seed=3, random_affine=True)
+    m = cls(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(dev)
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(B, cfg.in_channels, h, w, generator=g)
+    e = torch.randn(B, L, cfg.cross_attention_dim, generator=g)
+    e[:n0] = 0
+    c = None if cfg.projection_class_embeddings_input_dim is None else torch.randn(B, 1, cfg.projection_class_embeddings_input_dim, generator=g) * 0.4
+    p = torch.randn(1, cfg.block_out_channels[0], h, w, generator=g) * 0.1 if pose else None
+    t = torch.tensor([417], dtype=torch.int64, device=dev)
+    # Python schedule (tunes unseen shapes on the GPU on its first pass)
+    cond = m.prepare_conditioning(B, h, w, e.to(dev), None if c is None else c.to(dev), None if p is None else p.to(dev), zero_ctx_batches=n0)
+    x_in = ops.nchw_to_nhwc_bf16(s.to(dev), cpad=m._w["conv_in"].cin)
+    ref = m._forward_nhwc(x_in, B, h, w, t, cond).clone()
+    ref2 = m._forward_nhwc(x_in, B, h, w, t, cond).clone()
+    backend.sync()
+    assert torch.equal(ref, ref2)
+    # C schedule
+    ctx = UNetContext(m)
+    pose_b = ctx.prepare_conditioning(B, h, w, e, c, p, zero_ctx_batches=n0)
+    out = ctx.forward(x_in, t, None, B, h, w, pose_b)
+    backend.sync()
+    return sd, (s, e, c, p), ref, out
+
+
+def test_c_schedule_equals_python_schedule_stage2(backend):
+    cfg = UNetConfig.tiny()
+    B, h, w, L, n0 = (2, 8, 8, 5, 1) if backend.is_emu else (4, 16, 24, 9, 2)
+    sd, (s, e, c, p), ref, out = _run_both(backend, cfg, B, h, w, L, n0)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert torch.equal(out, ref), (out - ref).abs().max()
+    if not backend.is_emu:   # and the oracle, at the suite's forward tolerance
+        o = unet_forward(sd, cfg, s, torch.tensor(417), e, c, p)
+        rel = ((out.cpu() - o).norm() / o.norm()).item()
+        assert rel <= 2.5e-2, rel
+
+
+@pytest.mark.gpu
+def test_c_schedule_full_size_and_graph_capture(gpu_backend):
+    """The 868.9 M-parameter configuration at latent 64x88, UNet batch 8 (BASELINE.json configs[1]): C schedule == Python schedule, also
+    when the single C call is captured into a hipGraph and replayed with the timestep taken from a device table."""
+    cfg = UNetConfig()
+    sd, (s, e, c, p), ref, out = _run_both(gpu_backend, cfg, 8, 64, 88, 258, 4)
+    assert torch.equal(out, ref), (out - ref).abs().max()
+
+
+@pytest.mark.gpu
+def test_c_schedule_stage3_topology(gpu_backend):
+    """No class embedding, no pose (the stage-3 refinement UNet, in_channels 8), a latent that is not divisible by 8."""
+    cfg = UNetConfig.tiny(in_channels=8, class_embed_type=None, projection_class_embeddings_input_dim=None)
+    sd, _, ref, out = _run_both(gpu_backend, cfg, 2, 16, 12, 7, 1, cls=UNet2DConditionModel, pose=False)
+    assert torch.equal(out, ref), (out - ref).abs().max()
+
+
+def test_c_packers_equal_python_packers():
+    """pcdm_pack_linear / _conv3x3 / _geglu (what a C host uses) produce the very bytes pcdms_amd.ops.pack_* upload."""
+    import ctypes as C
+
+    from pcdms_amd import _lib
+    try:
+        lib = _lib.lib()
+    except RuntimeError:
+        from tests.emu import build_emu
+        _lib.use_library(build_emu.load())
+        lib = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    cpu = torch.device("cpu")
+    # linear (N not a multiple of 64)
+    N, K = 100, 128
+    w, b = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    pw = ops.pack_linear(w, b, cpu)
+    ow, ob = torch.empty(pw.Npad, K, dtype=torch.int16), torch.empty(pw.Npad)
+    assert lib.pcdm_pack_linear(w.data_ptr(), b.data_ptr(), N, K, 64, ow.data_ptr(), ob.data_ptr()) == pw.Npad
+    assert torch.equal(ow, pw.w.view(torch.int16)) and torch.equal(ob, pw.bias)
+    # conv3x3 (Cin padded 9 -> 64)
+    N, Cin = 64, 9
+    w, b = torch.randn(N, Cin, 3, 3, generator=g), torch.randn(N, generator=g)
+    pw = ops.pack_conv3x3(w, b, cpu)
+    ow, ob = torch.empty(pw.Npad, pw.K, dtype=torch.int16), torch.empty(pw.Npad)
+    kk, cc = C.c_int(0), C.c_int(0)
+    assert lib.pcdm_pack_conv3x3(w.contiguous().data_ptr(), b.data_ptr(), N, Cin, 64, ow.data_ptr(), ob.data_ptr(), C.addressof(kk), C.addressof(cc)) == pw.Npad
+    assert (kk.value, cc.value) == (pw.K, pw.cin) and torch.equal(ow, pw.w.view(torch.int16)) and torch.equal(ob, pw.bias)
+    # GEGLU (D not a multiple of 64)
+    D, K = 96, 64
+    w, b = torch.randn(2 * D, K, generator=g), torch.randn(2 * D, generator=g)
+    pw = ops.pack_geglu(w, b, cpu)
+    ow, ob = torch.empty(pw.Npad, K, dtype=torch.int16), torch.empty(pw.Npad)
+    assert lib.pcdm_pack_geglu(w.data_ptr(), b.data_ptr(), D, K, ow.data_ptr(), ob.data_ptr()) == pw.Npad and pw.N == D
+    assert torch.equal(ow, pw.w.view(torch.int16)) and torch.equal(ob, pw.bias)
+
+
+@pytest.mark.gpu
+def test_pipeline_with_c_schedule_equals_python_schedule(gpu_backend):
+    """The fused + hipGraph sampler with the UNet of every step run by ONE captured ``pcdm_unet_forward`` call: bit-identical final latents
+    to the default (Python-scheduled) capture, DDIM and UniPC."""
+    from oracle.pipeline import synth_inputs
+    from pcdms_amd.pipeline import Stage2_InpaintDiffusionPipeline
+    from pcdms_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
+    from tests.test_schedulers import SD21
+    cfg = UNetConfig.tiny()
+    dev = gpu_backend.device
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(synth_state_dict(cfg, seed=2, random_affine=True))
+    m.to(dev)
+    N, h, w, L, steps = 2, 16, 24, 9, 6
+    inp = synth_inputs(cfg, h, w, N, L_img=L)
+    kw = dict(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
+              st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
+              num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent")
+    for sched in (DDIMScheduler, UniPCMultistepScheduler):
+        a = Stage2_InpaintDiffusionPipeline(m, sched.from_config(SD21))(**kw).latents
+        pc = Stage2_InpaintDiffusionPipeline(m, sched.from_config(SD21), c_schedule=True)
+        b = pc(**kw).latents
+        assert pc._graph is not None and pc._st["ctx"] is not None
+        assert torch.equal(a, b), (sched.__name__, (a - b).abs().max())
+        assert torch.equal(pc(**kw).latents, b)      # replay

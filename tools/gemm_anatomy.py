@@ -73,8 +73,11 @@ if __name__ == "__main__":
                     run(M, N, K, tile, True)
         raise SystemExit(0)
     # thin-K linears (the prologue / epilogue share) and deep-K problems (the per-K-tile cost of the loop: main loop / (K / 64))
-    for (M, N, K) in [(45056, 320, 320), (45056, 960, 320), (45056, 320, 1280), (45056, 320, 5760), (11264, 1280, 5760), (11264, 640, 640)]:
-        for tile in (21, 17, 4):
+    for (M, N, K) in [(45056, 320, 320), (45056, 960, 320), (45056, 320, 1280), (45056, 320, 5760), (11264, 1280, 5760), (11264, 640, 640),
+                      (2816, 1280, 1280)]:
+        for tile in (21, 17, 4, 5, 18, 6):
+            if K > 1280 and tile in (5, 18, 6):
+                continue
             if (N % ops.TILE_SHAPES[tile][1]) == 0:
                 for res in ((True, False) if K <= 1280 else (False,)):
                     run(M, N, K, tile, res)
