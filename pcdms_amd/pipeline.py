@@ -333,6 +333,16 @@ class Stage2_InpaintDiffusionPipeline:
             st["mask"].copy_(mask)
         st["masked"].copy_(masked)
         st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
+        st["timesteps"].copy_(timesteps.to(dev))
+        st["coef"].copy_(self.scheduler.coefficient_table(device=dev) if unipc else self.scheduler.coefficient_table(eta, device=dev))
+        st["g"] = g
+        if st.get("gr", guidance_rescale) != guidance_rescale:
+            self._graph = None
+        st["gr"] = guidance_rescale
+        # pipe.unet replaced, weights re-packed (load_state_dict / .to), or a split-K workspace re-allocated: re-capture
+        w_gen = (id(unet), getattr(unet, "_pack_gen", 0), ops.workspace_generation(dev))
+        if st.get("w_gen") != w_gen:
+            self._graph = None
         st["ctx"] = None
         if self.c_schedule:
             from .unet_ctx import UNetContext
@@ -350,16 +360,6 @@ class Stage2_InpaintDiffusionPipeline:
             st["eps_c"] = st.get("eps_c") if st.get("eps_c") is not None and st["eps_c"].shape[0] == B else \
                 torch.empty(B, unet.config.out_channels, h, w, dtype=torch.float32, device=dev)
             st["ctx"] = self._ctx
-        st["timesteps"].copy_(timesteps.to(dev))
-        st["coef"].copy_(self.scheduler.coefficient_table(device=dev) if unipc else self.scheduler.coefficient_table(eta, device=dev))
-        st["g"] = g
-        if st.get("gr", guidance_rescale) != guidance_rescale:
-            self._graph = None
-        st["gr"] = guidance_rescale
-        # pipe.unet replaced, weights re-packed (load_state_dict / .to), or a split-K workspace re-allocated: re-capture
-        w_gen = (id(unet), getattr(unet, "_pack_gen", 0), ops.workspace_generation(dev))
-        if st.get("w_gen") != w_gen:
-            self._graph = None
         st["step"].zero_()
         self._zero_history(st)
         self._st, self._graph_key = st, key

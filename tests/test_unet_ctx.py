@@ -107,8 +107,7 @@ def test_c_packers_equal_python_packers():
     assert torch.equal(ow, pw.w.view(torch.int16)) and torch.equal(ob, pw.bias)
 
 
-@pytest.mark.gpu
-def test_pipeline_with_c_schedule_equals_python_schedule(gpu_backend):
+def test_pipeline_with_c_schedule_equals_python_schedule(backend):
     """The fused + hipGraph sampler with the UNet of every step run by ONE captured ``pcdm_unet_forward`` call: bit-identical final latents
     to the default (Python-scheduled) capture, DDIM and UniPC."""
     from oracle.pipeline import synth_inputs
@@ -116,19 +115,21 @@ def test_pipeline_with_c_schedule_equals_python_schedule(gpu_backend):
     from pcdms_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
     from tests.test_schedulers import SD21
     cfg = UNetConfig.tiny()
-    dev = gpu_backend.device
+    dev = backend.device
     m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
     m.load_state_dict(synth_state_dict(cfg, seed=2, random_affine=True))
     m.to(dev)
-    N, h, w, L, steps = 2, 16, 24, 9, 6
+    N, h, w, L, steps = (1, 8, 8, 4, 1) if backend.is_emu else (2, 16, 24, 9, 6)
     inp = synth_inputs(cfg, h, w, N, L_img=L)
     kw = dict(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
               st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
               num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent")
-    for sched in (DDIMScheduler, UniPCMultistepScheduler):
+    for sched in (DDIMScheduler,) if backend.is_emu else (DDIMScheduler, UniPCMultistepScheduler):
         a = Stage2_InpaintDiffusionPipeline(m, sched.from_config(SD21))(**kw).latents
         pc = Stage2_InpaintDiffusionPipeline(m, sched.from_config(SD21), c_schedule=True)
         b = pc(**kw).latents
-        assert pc._graph is not None and pc._st["ctx"] is not None
+        backend.sync()
+        assert pc._st["ctx"] is not None and (backend.is_emu or pc._graph is not None)
         assert torch.equal(a, b), (sched.__name__, (a - b).abs().max())
-        assert torch.equal(pc(**kw).latents, b)      # replay
+        if not backend.is_emu:
+            assert torch.equal(pc(**kw).latents, b)      # replay
