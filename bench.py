@@ -166,7 +166,8 @@ def main():
                                "868.9M-param UNet, 258 context tokens, bf16 MFMA / fp32 accumulate",
                    "global_batch": world * N, "ms_per_denoise_step": round(ms_per_step / args.ddim_steps, 3),
                    "parallelism": f"dp{world}", "hipgraph": not args.no_graph, "setup_s": round(setup_s, 1),
-                   "rccl_world_size": dist.get_world_size() if use_dist else 1, "attention": args.attn,
+                   "rccl_world_size": dist.get_world_size() if use_dist else 1, "process_group": dist.get_backend() if use_dist else None,
+                   "attention": args.attn,
                    "e2e_tflops_per_gpu": round(e2e_tflops, 1),
                    "flops_note": "e2e_tflops_per_gpu and roofline.e2e_frac credit the UN-HOISTED algorithmic FLOPs of SURVEY.md §8d "
                                  "(118.84 TFLOP per image); executed FLOPs are ~3.5% lower: the cross-attention K/V projections run once "

@@ -75,3 +75,27 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
 def test_entry_points_exist():
     src = (ROOT / "__graft_entry__.py").read_text()
     assert "def build(" in src and "def smoke(" in src and "gfx950" in (ROOT / "pcdms_amd" / "build.py").read_text()
+
+
+@pytest.mark.gpu
+def test_bench_runs_with_a_one_rank_rccl_group():
+    """`PCDM_BENCH_FORCE_DIST=1 python bench.py --gpus 1`: the code path the driver's N > 1 runs take -- RCCL process group on
+    127.0.0.1, hipGraph capture with the group alive, barrier + MAX all-reduce around the timed region, the rank gather -- executed on
+    the one GPU a test box has.  Short schedule (10 DDIM steps): this checks the plumbing, not the number."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PCDM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--ddim-steps", "10",
+                        "--no-cpu-baseline", "--no-roofline", "--no-vae"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["value"] > 0
+    assert d["config"]["rccl_world_size"] == 1 and d["config"]["process_group"] == "nccl" and d["config"]["hipgraph"] is True
