@@ -1005,7 +1005,9 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if ((int64_t)p->Npad * (p->ldw > 0 ? p->ldw : p->K) * 2 >= lim) return -2;
     if (p->conv ? ((int64_t)p->B * p->Hi * p->Wi * p->cin * 2 + ((int64_t)p->Wi + 1) * p->cin * 2 >= lim)
                 : ((int64_t)p->M * p->lda * 2 >= lim || (p->a2 && (int64_t)p->M * p->lda2 * 2 >= lim))) return -2;
-    if ((int64_t)p->M * (p->ldo > 0 ? p->ldo : p->N) * 4 >= lim || (p->residual && (int64_t)p->M * (p->ldr > 0 ? p->ldr : p->N) * 2 >= lim))
+    const int64_t out_esz = p->epilogue == PCDM_EPI_NCHW_F32 ? 4 : 2;   // (fp32 only there; the x4 applied to every epilogue refused the
+                                                                         //  VAE decoder's 2.9 M x 256 bf16 upsampling convs at 8 samples)
+    if ((int64_t)p->M * (p->ldo > 0 ? p->ldo : p->N) * out_esz >= lim || (p->residual && (int64_t)p->M * (p->ldr > 0 ? p->ldr : p->N) * 2 >= lim))
         return -2;   // (32-bit offsets in the epilogue's buffer stores / loads)
     GemmArgs a;
     a.a = (const u16*)p->a;

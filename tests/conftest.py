@@ -20,7 +20,28 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """``-m "not gpu"`` (the CPU suite: ten of its tests each run a whole UNet under the single-threaded lane emulator, 30-70 s apiece)
+    is spread over a few pytest-xdist workers unless the caller chose ``-n`` / ``-p no:xdist`` himself; the GPU suite is never
+    parallelised (one GPU, timing-sensitive tests)."""
+    import os
+    if config.getoption("markexpr", "") != "not gpu" or os.environ.get("PYTEST_XDIST_WORKER") or os.environ.get("PCDM_TEST_SERIAL"):
+        return None
+    if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None:
+        return None
+    from tests.emu import build_emu
+    build_emu.build()                      # once, here: the workers must not race on the emulator build
+    config.option.numprocesses = min(6, max(1, (os.cpu_count() or 2) // 2))
+    config.option.dist = "load"
+    return None
+
+
 def pytest_configure(config):
+    import os
+    if os.environ.get("PYTEST_XDIST_WORKER"):   # share the host cores between the workers instead of oversubscribing them
+        n = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "1"))
+        torch.set_num_threads(max(1, (os.cpu_count() or n) // n))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
 

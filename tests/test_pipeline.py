@@ -46,7 +46,8 @@ def _call(pipe, inp, dev, N, steps, h, w, **kw):
     return pipe(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev),
                 s_img_proj_f=inp["s_img_proj_f"].to(dev), st_pose_f=inp["st_pose_f"].to(dev),
                 pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
-                num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent", **kw).latents
+                num_images_per_prompt=N, guidance_scale=kw.pop("guidance_scale", 2.0), num_inference_steps=steps, output_type="latent",
+                **kw).latents
 
 
 def test_pipeline_ddim_vs_oracle(backend):
@@ -70,6 +71,34 @@ def test_pipeline_ddim_vs_oracle(backend):
                              num_inference_steps=steps, **inp2)
         out2 = _call(pipe, inp2, backend.device, N, steps, h, w)
         assert _rel(out2, ref2) <= 3e-2
+
+
+@pytest.mark.parametrize("sched", ["ddim", "unipc"])
+def test_pipeline_without_cfg(backend, sched):
+    """guidance_scale = 1 (ref stage2_inpaint_pipeline.py:433 ``do_classifier_free_guidance = guidance_scale > 1.0``): the UNet runs on N
+    rows, nothing is doubled, no zero-context half exists and eps is used as it comes; literal loop and fused (graph) path against the
+    oracle, and N = 1 (the smallest batch the reference accepts)."""
+    if backend.is_emu and sched == "unipc":
+        pytest.skip("CPU-suite budget: under the emulator the DDIM case covers the no-CFG plumbing; UniPC runs on the GPU")
+    cfg = UNetConfig.tiny()
+    N, h, w, L, steps = (1, 8, 8, 4, 1) if backend.is_emu else (1, 16, 24, 9, 6)
+    sd, m = _build(backend, cfg, seed=3)
+    inp = synth_inputs(cfg, h, w, N, L_img=L)
+    O, S = (DDIMOracle, DDIMScheduler) if sched == "ddim" else (UniPCOracle, UniPCMultistepScheduler)
+    ref = stage2_sample(sd, cfg, O(), num_images_per_prompt=N, guidance_scale=1.0, num_inference_steps=steps, **inp)
+    pipe = Stage2_InpaintDiffusionPipeline(m, S.from_config(SD21))
+    lit = _call(pipe, inp, backend.device, N, steps, h, w, mode="reference", guidance_scale=1.0)
+    fused = _call(pipe, inp, backend.device, N, steps, h, w, guidance_scale=1.0)
+    backend.sync()
+    assert lit.shape == (N, 4, h, w) and _rel(lit, ref) <= 3e-2, _rel(lit, ref)
+    assert _rel(fused, ref) <= 3e-2 and _same_path(fused, lit, steps == 1)
+    if backend.is_emu:
+        return
+    # and the guided call right after it on the same pipeline object (other batch, other graph): no state leaks between the two
+    ref_g = stage2_sample(sd, cfg, O(), num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, **inp)
+    guided = _call(pipe, inp, backend.device, N, steps, h, w)
+    backend.sync()
+    assert _rel(guided, ref_g) <= 3e-2, _rel(guided, ref_g)
 
 
 def test_pipeline_unipc_and_identities(backend):
