@@ -17,7 +17,9 @@ What is compared (reference: /root/reference/src/pipelines/stage2_inpaint_pipeli
 * configs[2]'s per-GPU share (N = 8, UNet batch 16): forwards at TWO oracle states (step 0: ``b16_eps``; step 25:
   ``fullsize_b16_mid.npz``) and a 50-step N = 8 hipGraph run whose first four samples reproduce the oracle's N = 4 trajectory
   (samples are independent: same pair, per-sample noise) and whose two halves are mutually consistent;
-* configs[4]'s per-GPU share (fp8 attention, N = 16, UNet batch 32): fp8 forward vs the bf16 path, and run-to-run determinism.
+* configs[4]'s per-GPU share (fp8 attention, N = 16, UNet batch 32): fp8 forward vs the bf16 path, and run-to-run determinism;
+* configs[0] -- the reference's own CPU-runnable case (one 256x256 pair: latent 32x64, N = 1, 20 DDIM steps): the COMPLETE call
+  against ``fullsize_config0.npz`` (same weights; M = 4096 rows, UNet batch 2 -- other tiles, other split-K than configs[1]).
 
 Tolerances are stated here and were set from the measured values on MI355X (recorded in DESIGN.md §5)."""
 from __future__ import annotations
@@ -263,3 +265,40 @@ def test_configs4_share_fp8_batch32(full):
     print("configs[4] share, UNet batch 32: fp8-attention vs bf16-attention guided eps rel-L2", round(r, 5))
     assert torch.equal(e1, e2) and bool(torch.isfinite(e1).all())
     assert r <= FP8_VS_BF16_TOL, r
+
+
+@pytest.mark.gpu
+def test_config0_complete_run(full):
+    """BASELINE.json configs[0]: 1 pair at 256x256 (latent 32x64), num_images_per_prompt = 1, 20 DDIM steps, guidance 2.0 -- the whole
+    call on the full-size weights against the fp32 oracle's run of the same call (tests/golden/make_fullsize_config0_fixture.py)."""
+    _, cfg, m, dev = full
+    fx = np.load(Path(__file__).resolve().parent / "golden" / "fullsize_config0.npz")
+    assert str(fx["torch_version"]) == torch.__version__
+    N, h, w, steps = 1, 32, 64, int(fx["steps"])
+    inp = synth_inputs(cfg, h, w, N)
+    assert np.array_equal(inp["latents"].numpy(), fx["lat_0"])
+    # single forwards at the oracle's own states
+    fw = {}
+    sch = DDIMOracle()
+    sch.set_timesteps(steps)
+    for i in (0, 10, 19):
+        eps = _guided_eps(m, cfg, inp, torch.from_numpy(fx[f"lat_{i}"]), int(sch.timesteps[i]), N, dev)
+        fw[i] = _rel(eps, fx[f"eps_{i}"].astype(np.float32))
+    print("configs[0] guided eps rel-L2 at oracle states:", {k: round(v, 5) for k, v in fw.items()})
+    assert max(fw.values()) <= FWD_TOL, fw
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    seen = {}
+    out = pipe(height=h * 8, width=w * 8, masked_latents=inp["masked_latents"].to(dev), s_img_proj_f=inp["s_img_proj_f"].to(dev),
+               st_pose_f=inp["st_pose_f"].to(dev), pred_t_img_embed=inp["pred_t_img_embed"].to(dev), latents=inp["latents"].to(dev),
+               num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=steps, output_type="latent",
+               callback=lambda i, t, lat: seen.__setitem__(i + 1, lat)).latents
+    cx = _ddim_x_coefficients(steps)
+    lat0 = torch.from_numpy(fx["lat_0"])
+    rels, parts = {}, {}
+    for i in (5, 10, 15, steps):
+        hip = (seen[i] if i < steps else out).float().cpu()
+        ref = torch.from_numpy(fx[f"lat_{i}"] if i < steps else fx["lat_final"])
+        rels[i] = ((hip - ref).norm() / ref.norm()).item()
+        parts[i] = (((hip - cx[i] * lat0) - (ref - cx[i] * lat0)).norm() / (ref - cx[i] * lat0).norm()).item()
+    print("configs[0] 20-step run rel-L2:", {k: round(v, 5) for k, v in rels.items()}, "eps-driven part:", {k: round(v, 5) for k, v in parts.items()})
+    assert max(rels.values()) <= 2 * TRAJ_TOL and max(parts.values()) <= 2 * EPS_PART_TOL, (rels, parts)   # (20 coarse steps: larger eps weight per step)
