@@ -116,8 +116,14 @@ __device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t so
 __device__ __forceinline__ u32x4 buf_load16(BufRsrc r, uint32_t voff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, 0));
 }
+// PCDM_STORE_AUX: cache-policy bits of the epilogues' output stores (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  A/B knob
+// (PCDM_BUILD_DEFINES="PCDM_STORE_AUX=2"): non-temporal output stores, so that an epilogue's write stream does not evict the weight /
+// activation tiles the other workgroups of the launch are still re-reading from the L2
+#ifndef PCDM_STORE_AUX
+#define PCDM_STORE_AUX 0
+#endif
 __device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r.r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r.r, voff, 0, PCDM_STORE_AUX);
 }
 #endif
 

@@ -95,15 +95,18 @@ __device__ __forceinline__ void wait_lds_rg() {   // s_waitcnt lgkmcnt(0), visib
 // WGM x WGN waves; a wave owns FMW row blocks of 16 and, per N tile, BN / WGN columns; NSTG ring stages of [BN][64]; LNF: folded LayerNorm;
 // GLU: the gated-linear-unit epilogue (its own instantiation: with all three epilogues in one kernel the lane constants hipcc hoists out of
 // the N-tile loop for each of them pushed the 48 x 64 wave tile over 256 VGPRs -- spills whose reloads sit behind the epilogue's stores)
+// NW = 4 (256 threads, __launch_bounds__(256, 2)): TWO workgroups per CU, one wave of each per SIMD -- two barrier domains, so that one
+// workgroup's stage wait / barrier / DMA issue can sit under the other's MFMAs.  Such a launch splits the N tiles over gridDim.y
+// workgroups per row block (there are only 235 row blocks of 192 at M = 45056; the A rows are then read once per N split).
 template <int WGM, int WGN, int FMW, int BN, int NSTG, bool LNF, bool GLU>
-__global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WGM* WGN * 64, WGM* WGN == 4 ? 2 : 1) void rowgemm_kernel(const GemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * FMW * 16;
     constexpr int WNC = BN / WGN;          // columns of an N tile per wave
     constexpr int FN = WNC / 16;           // B fragments per wave per k-step
     constexpr int DPW = BN / 8 / NW;       // LDS-DMA instructions per wave per stage (8 rows of 128 B each)
     constexpr int EPW = WNC + 4;           // fp32 pitch of the wave-private epilogue tile (16 rows)
-    static_assert(NW == 8 && BN % (8 * NW) == 0 && WNC % 16 == 0 && (WNC == 32 || WNC == 64), "shape");
+    static_assert((NW == 8 || NW == 4) && BN % (8 * NW) == 0 && WNC % 16 == 0 && (WNC == 32 || WNC == 64), "shape");
     static_assert(NSTG >= 3 && (NSTG - 2) * DPW <= 14, "ring depth");   // (stages q + 1 .. q + NSTG - 2 in flight behind the one awaited)
     PCDM_DYN_SMEM(smem);
     u16* Ws = (u16*)smem;                                  // [NSTG][BN][64]  (unpadded, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
@@ -137,7 +140,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         const int rl = (wave * DPW + i) * 8 + (lane >> 3);
         b_off[i] = (uint32_t)((int64_t)rl * p.ldw * 2) + (uint32_t)(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
     }
-    const int NT = p.Npad / BN;
+    // this workgroup's N tiles: [nt_lo, nt_lo + NT) of the Npad / BN tiles (gridDim.y == 1: all of them)
+    const int NT_all = p.Npad / BN;
+    const int nt_lo = (int)((int64_t)blockIdx.y * NT_all / gridDim.y);
+    const int NT = (int)((int64_t)(blockIdx.y + 1) * NT_all / gridDim.y) - nt_lo;
     // Every workgroup walks ALL N tiles, i.e. streams the whole of W -- and with one workgroup per CU starting together they would all ask
     // the L2s for the SAME 16 KiB at the same moment, stage after stage (one channel serving a line 32 times over while the others idle).
     // Each workgroup therefore starts its walk at a different N tile (p.debug & 16: all start at tile 0, for A/B runs).
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     const int Q = skip ? 0 : NT * kNKT;
     auto issue = [&](int q) {
         const int nt_ = q / kNKT, kt = q - nt_ * kNKT;
-        const int nt = nt_ + rot < NT ? nt_ + rot : nt_ + rot - NT;
+        const int nt = nt_lo + (nt_ + rot < NT ? nt_ + rot : nt_ + rot - NT);
         const uint32_t soff = (uint32_t)(((int64_t)nt * BN * p.ldw + kt * 64) * 2);
         u16* ws = Ws + (q % NSTG) * (BN * 64) + (wave * DPW) * 8 * 64;
 #pragma unroll
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
         }
     };
     auto epilogue = [&](int nt_) {
-        const int nt = nt_ + rot < NT ? nt_ + rot : nt_ + rot - NT;
+        const int nt = nt_lo + (nt_ + rot < NT ? nt_ + rot : nt_ + rot - NT);
         const int n0w = nt * BN + wn * WNC;                 // first (packed) column of this wave's tile
         if constexpr (GLU) {
             if constexpr (WNC == 64) {
@@ -429,13 +435,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void rowgemm_kernel(const GemmArgs p
     }
 #ifndef PCDM_EMU
     if (stamps && p.ws && lane == 0) {
-        unsigned long long* o = (unsigned long long*)p.ws + ((int64_t)blockIdx.x * NW + wave) * 8;
+        unsigned long long* o = (unsigned long long*)p.ws + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
         for (int i = 0; i < 6; ++i) o[i] = tk[i];
     }
 #endif
 }
 
-template <int WGM, int WGN, int FMW, int BN, int NSTG>
+template <int WGM, int WGN, int FMW, int BN, int NSTG, int NSPLIT_WGS = 0>
 int launch_rg(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = WGM * FMW * 16, WNC = BN / WGN, NW = WGM * WGN;
     constexpr int smem_fixed = NSTG * BN * 64 * (int)sizeof(u16) + NW * 16 * (WNC + 4) * (int)sizeof(float);
@@ -443,7 +449,14 @@ int launch_rg(const GemmArgs& a, hipStream_t st) {
     const int smem = smem_fixed + (2 * a.Npad + NW * FMW * 32) * (int)sizeof(float);   // + bias, the folded weights' row sums, row statistics
     if (a.epilogue == PCDM_EPI_GEGLU && WNC != 64) return -1;
     if (a.epilogue == PCDM_EPI_SPLIT_VT && (a.vt_col0 % WNC || a.rows_per_batch % 16 || (a.ldo2 & 7) || a.M % 16)) return -1;
-    const int grid = (a.M + BM - 1) / BM;
+    const int gx = (a.M + BM - 1) / BM;
+    // NSPLIT_WGS > 0: split the N tiles over enough workgroups per row block to reach that many workgroups in total (two per CU)
+    int gy = 1;
+    if (NSPLIT_WGS > 0) {
+        gy = (NSPLIT_WGS + gx / 2) / gx;
+        gy = gy < 1 ? 1 : (gy > a.Npad / BN ? a.Npad / BN : gy);
+    }
+    const dim3 grid(gx, gy);
     const int smem_max = smem_fixed + (2 * 2560 + NW * FMW * 32) * (int)sizeof(float);
 #define PCDM_RG_LAUNCH(LN_, GLU_)                                                                                                      \
     do {                                                                                                                               \
@@ -453,7 +466,7 @@ int launch_rg(const GemmArgs& a, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);                                          \
             attr_done = true;                                                                                                          \
         }                                                                                                                              \
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, LN_, GLU_>), dim3(grid), dim3(NW * 64), smem, st, a);     \
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(rowgemm_kernel<WGM, WGN, FMW, BN, NSTG, LN_, GLU_>), grid, dim3(NW * 64), smem, st, a);     \
     } while (0)
     const bool glu = a.epilogue == PCDM_EPI_GEGLU;
     if constexpr (WNC == 64) {
@@ -484,6 +497,8 @@ int pcdm_gemm_detail::launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st
         case 31: return launch_rg<4, 2, 3, 128, 6>(a, st);   // 192 rows, N tiles of 128 (waves 48 x 64: GEGLU-capable), 96 + 34 KiB
         case 32: return launch_rg<4, 2, 3, 64, 8>(a, st);    // 192 rows, N tiles of 64 (waves 48 x 32), 64 + 18 KiB
         case 33: return launch_rg<2, 4, 3, 128, 6>(a, st);   // 96 rows, N tiles of 128 (waves 48 x 32): M = 22528 -> 235 workgroups
+        case 34: return launch_rg<4, 1, 3, 64, 5, 512>(a, st);  // FOUR waves (48 x 64 each), 192 rows, N tiles of 64, two workgroups per CU
+                                                               // (40 + 17 + <= 22 KiB each), N split over 512 / row-blocks workgroups
 #ifdef PCDM_DEV_ROWGEMM_VARIANTS
         case 35: return launch_rg<4, 2, 3, 128, 4>(a, st);   // as 31 with a 4-stage ring
         case 36: return launch_rg<4, 2, 3, 128, 3>(a, st);   // as 31 with a 3-stage ring

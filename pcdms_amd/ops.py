@@ -346,13 +346,13 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
     return out
 
 
-ROWGEMM_TILES = (31, 32, 33)   # rowgemm.hip (K = 320): id -> (BM, BN) below
+ROWGEMM_TILES = (31, 32, 33, 34)   # rowgemm.hip (K = 320): id -> (BM, BN) below
 # gemm.hip dispatch_tile(): id -> (BM, BN)
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),
                15: (128, 64), 16: (512, 64), 17: (256, 256), 18: (128, 128),
                21: (192, 320), 26: (192, 256),
-               31: (192, 128), 32: (192, 64), 33: (96, 128)}
+               31: (192, 128), 32: (192, 64), 33: (96, 128), 34: (192, 64)}
 _TUNED: dict = {}
 _WS: dict = {}
 

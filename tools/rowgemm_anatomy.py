@@ -74,6 +74,9 @@ def run(name, M, N, tile, epi, ln, extra=0):
 
 
 if __name__ == "__main__":
+    run("ff1 (4 waves, 2 WGs/CU)", 45056, 1280, 34, ops.EPI_GEGLU, True)
+    run("qkv (4 waves, 2 WGs/CU)", 45056, 960, 34, ops.EPI_SPLIT_VT, True)
+    run("lin (4 waves, 2 WGs/CU)", 45056, 320, 34, ops.EPI_STORE, False)
     run("ff1 ", 45056, 1280, 31, ops.EPI_GEGLU, True)
     run("ff1 dma-both-first", 45056, 1280, 31, ops.EPI_GEGLU, True, 64)
     run("lin dma-both-first", 45056, 2560, 31, ops.EPI_STORE, False, 64)
