@@ -69,6 +69,19 @@ __device__ __forceinline__ void wait_stage(int n) {
 #endif
 }
 
+// the same wait with a compile-time count: ONE instruction.  (The run-time form above compiles to a tree of ~35 scalar compares and
+// branches through hipcc's structured-control-flow lowering -- a few hundred cycles per ring stage; the steady state of the ring, whose
+// count depends only on the K-tile index inside the N tile, therefore uses this one.)
+template <int N>
+__device__ __forceinline__ void wait_stage_const() {
+#ifndef PCDM_EMU
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 __device__ __forceinline__ void stage_barrier() {
 #ifdef PCDM_EMU
     __syncthreads();
@@ -388,9 +401,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, WGM* WGN == 4 ? 2 : 1) void rowgemm_
     };
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, 1> B1;
+    constexpr int EP_STORES = GLU ? FMW : FMW * (WNC / 32);   // (= n_ep_stores)
     for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int kt = 0; kt < kNKT; ++kt) {
+        auto stage = [&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
             const int q = nt * kNKT + kt;
             // awaited stage: q + 1 (q itself at the very end).  Operations this wave may leave in flight: the ring stages younger than
             // that, and the stores of the epilogues it ran since it issued the awaited stage (in iteration lo = target - NSTG + 1, or in
@@ -399,7 +413,14 @@ __global__ __launch_bounds__(WGM* WGN * 64, WGM* WGN == 4 ? 2 : 1) void rowgemm_
             const int younger = (Q - 1 - tgt) < (NSTG - 2 - (tgt - q)) ? (Q - 1 - tgt) : (NSTG - 2 - (tgt - q));
             const int lo = tgt - (NSTG - 1) > 0 ? tgt - (NSTG - 1) : 0;
             RG_ACC(4);
-            wait_stage(younger * DPW + (q / kNKT - lo / kNKT) * n_ep_stores);
+            // steady state (NSTG - 3 younger stages exist, and the epilogues between the issue of the awaited stage -- iteration
+            // lo = q + 2 - NSTG -- and now have all happened): younger == NSTG - 3 and q / kNKT - lo / kNKT == ceil((NSTG - 2 - kt) / kNKT), a
+            // compile-time count
+            constexpr int NEP = NSTG - 2 - kt > 0 ? (NSTG - 2 - kt + kNKT - 1) / kNKT : 0;
+            if (nt >= NEP && q + NSTG - 1 <= Q && !(p.debug & 128))
+                wait_stage_const<(NSTG - 3) * DPW + NEP * EP_STORES>();
+            else
+                wait_stage(younger * DPW + (q / kNKT - lo / kNKT) * n_ep_stores);   // (p.debug & 128: always this form, for A/B runs)
             RG_ACC(1);   // waiting for this wave's part of the stage to land
             stage_barrier();
             RG_ACC(5);   // waiting for the other waves
@@ -428,7 +449,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, WGM* WGN == 4 ? 2 : 1) void rowgemm_
             PCDM_SCHED_BARRIER();
             if (!dma_first && q + NSTG - 1 < Q) issue(q + NSTG - 1);
             RG_ACC(2);   // fragment reads + MFMAs (+ the late DMA issue)
-        }
+        };
+        static_assert(kNKT == 5, "K = 320");
+        stage(std::integral_constant<int, 0>());
+        stage(std::integral_constant<int, 1>());
+        stage(std::integral_constant<int, 2>());
+        stage(std::integral_constant<int, 3>());
+        stage(std::integral_constant<int, 4>());
         epilogue(nt);
         zero_acc();
         RG_ACC(3);       // epilogue
@@ -502,6 +529,9 @@ int pcdm_gemm_detail::launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st
 #ifdef PCDM_DEV_ROWGEMM_VARIANTS
         case 35: return launch_rg<4, 2, 3, 128, 4>(a, st);   // as 31 with a 4-stage ring
         case 36: return launch_rg<4, 2, 3, 128, 3>(a, st);   // as 31 with a 3-stage ring
+        case 37: return launch_rg<4, 1, 3, 64, 3, 512>(a, st);   // as 34 with a 3-stage ring
+        case 38: return launch_rg<4, 1, 3, 64, 4, 512>(a, st);   // as 34 with a 4-stage ring
+        case 39: return launch_rg<4, 1, 3, 64, 5, 768>(a, st);   // as 34 with the N tiles split three ways at M = 45056
 #endif
         default: return -1;
     }
