@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent.parent
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r2_bench_fast_box.json"])
+@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r2_bench_fast_box.json", "r3_bench.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = (ROOT / "profiles" / name).read_text().strip().splitlines()[-1]
     d = json.loads(line)
@@ -33,8 +33,12 @@ def test_committed_bench_line_has_the_contract_fields(name):
     assert abs(r["achieved"] - r["alg_gflop_per_launch"] / r["avg_launch_us"] * 1e3)   # GFLOP / us = 1000 TFLOP/s < 0.02 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    if name.startswith("r2"):   # round 2: whole-path fraction, the RCCL world size, the full configs[0] CPU run
+    if name.startswith(("r2", "r3")):   # round 2: whole-path fraction, the RCCL world size, the full configs[0] CPU run
         assert 0 < r["e2e_frac"] < 1 and cfg["rccl_world_size"] == d["n_gpus"] and c["config1"]["seconds"] > 0
+    if name.startswith("r3"):   # round 3: executed-FLOP fraction, CPU baseline at physical-core thread counts, traffic only with a source stamp
+        assert 0 < r["e2e_frac_executed"] < r["e2e_frac"] and "process_group" in cfg
+        assert c["cores"] in (c["host"]["cores_per_socket"], c["host"]["cores_per_socket"] // 2) and str(c["cores"]) in c["per_thread_count"]
+        assert r["traffic"] is None or "kernel_src_sha256" in json.loads((ROOT / "profiles" / "gemm_traffic.json").read_text())
 
 
 def test_bench_flags_and_defaults():
