@@ -196,7 +196,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
     ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  With ``pw_ln`` (the same Linear packed by ``pack_linear_ln`` /
-    ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..33, K = 320) needs no LayerNorm pass
+    ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..34, K = 320; 34 = four waves, two workgroups per CU: the one in use) needs no LayerNorm pass
     at all -- it takes the row statistics from the rows it holds; for every other tile the rows go through ``pcdm_layernorm`` into
     ``ln_buf`` [M, K] first (the tuner times both forms, the LayerNorm launch included, and keeps the faster)."""
     if ln is not None and conv is None and a2 is None and ln_buf is not None:
