@@ -416,7 +416,13 @@ extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w,
     }
     if (pose) {
         if (pose_b != 1 && pose_b != B) return -1;
-        R.chk(pcdm_nchw_f32_to_nhwc_bf16(pose, R.buf("pose"), pose_b, c.block_out_channels[0], c.block_out_channels[0], h * w, s), "nchw_to_nhwc");
+        // one NHWC copy per batch entry, also for a batch-1 pose feature: conv_in then adds it as a plain residual (res_mod = M: the
+        // 16-byte-per-lane epilogue; a broadcast residual takes the per-element one)
+        const int C0p = c.block_out_channels[0];
+        if (pose_b == B) R.chk(pcdm_nchw_f32_to_nhwc_bf16(pose, R.buf("pose"), B, C0p, C0p, h * w, s), "nchw_to_nhwc");
+        else
+            for (int b = 0; b < B; ++b)
+                R.chk(pcdm_nchw_f32_to_nhwc_bf16(pose, R.buf<char>("pose") + (int64_t)b * h * w * C0p * 2, 1, C0p, C0p, h * w, s), "nchw_to_nhwc");
     }
     (void)temb_dim;
     const int Bc = B - n0;
@@ -555,7 +561,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     {
         Run::G g;
         g.conv = 1; g.B = B; g.Hi = h; g.Wi = w; g.Ho = h; g.Wo = w;
-        if (pose_b > 0) { g.residual = R.buf("pose"); g.ldr = C0; g.res_mod = pose_b * HW; }
+        if (pose_b > 0) { g.residual = R.buf("pose"); g.ldr = C0; g.res_mod = B * HW; }   // (prepare_conditioning wrote B entries)
         R.gemm(x_in, 0, B * HW, R.pw("conv_in"), R.buf("skip0"), g);
         x = R.buf("skip0");
     }

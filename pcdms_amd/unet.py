@@ -416,7 +416,17 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             pose = my_pose_cond
             if pose.dim() != 4 or pose.shape[0] not in (1, B) or tuple(pose.shape[1:]) != (boc[0], h, w):
                 raise ValueError(f"my_pose_cond must be [1|{B},{boc[0]},{h},{w}], got {tuple(pose.shape)}")
-            cond.pose_nhwc = ops.nchw_to_nhwc_bf16(pose.to(dev), self._buf("pose", (pose.shape[0], h, w, boc[0])))
+            # one NHWC copy per batch entry, also for a batch-1 pose feature (the reference doubles / repeats it, ref pipeline :457-459): the
+            # conv_in epilogue then adds it as a plain residual (res_mod = M) on the 16-byte-per-lane path -- a broadcast residual
+            # (res_mod = h w) takes the kernel's per-element epilogue, 59 against ~30 us for the launch
+            buf = self._buf("pose", (B, h, w, boc[0]))
+            pose = pose.to(dev)
+            if pose.shape[0] == B:
+                ops.nchw_to_nhwc_bf16(pose, buf)
+            else:
+                for b in range(B):
+                    ops.nchw_to_nhwc_bf16(pose, buf[b:b + 1])
+            cond.pose_nhwc = buf
         e32 = ehs.to(dev, torch.float32).contiguous()
         if zero_ctx_batches is None:   # leading all-zero batch entries (bare callers; the pipelines know and say so)
             nz = (e32.reshape(B, -1) != 0).any(dim=1).to(torch.int32)
