@@ -8,8 +8,12 @@
 // (tools/gemm_anatomy.py: 13.8 k cycles of K loop against 4.5 k + 10-22 k of prologue / epilogue per tile), every 128x128 output tile
 // re-stages its A rows, and the LayerNorm in front of to_q|k|v / to_q / GEGLU is a launch of its own (one read + one write of the
 // tensor).  Here:
-//  * one workgroup = 8 waves as WGM x WGN; a wave owns FMW*16 = 48 rows for the whole launch and keeps them as MFMA operand fragments
-//    in registers (16x16x32: 10 k-steps x 3 row blocks x 4 VGPRs = 120); the A rows are read from HBM ONCE, straight into registers;
+//  * one workgroup = WGM x WGN waves; a wave owns FMW*16 = 48 rows for the whole launch and keeps them as MFMA operand fragments
+//    in registers (16x16x32: 10 k-steps x 3 row blocks x 4 VGPRs = 120); the A rows are read straight into registers.  The instance the
+//    product uses (tile 34) has FOUR waves and runs TWO workgroups per CU (__launch_bounds__(256, 2), 80 KB of LDS each, the N tiles
+//    split over gridDim.y): one wave of each workgroup per SIMD = two barrier domains per CU, so that one workgroup's stage barrier,
+//    DMA issue and epilogue sit under the other's MFMAs.  The 8-wave one-workgroup-per-CU instances (tiles 31-33) never beat the tiled
+//    kernel (tools/bench_rowgemm.py, profiles/r3_bench_rowgemm.txt);
 //  * LayerNorm (optional, template LNF) is FOLDED: gamma goes into the weights and beta into the bias when they are packed
 //    (W' = W diag(gamma), b' = b + W beta), and since LN(x) W'^T = rstd (x W'^T - mean * rowsum(W')), all that is left at run time is
 //    a per-row mean / rstd -- taken from the registers right after the load (a row is spread over 4 lanes: local sums, two
@@ -20,8 +24,8 @@
 //    gemm.hip) through ONE ring of NSTG stages of 64 k that runs across N-tile boundaries: the next tile's first stages are in flight
 //    while the current tile's epilogue runs, 5-7 stages (40-96 KiB) outstanding per CU; only B fragments are read from LDS
 //    (FN ds_read_b128 per FN*FMW MFMAs);
-//  * M = 45056 gives 235 workgroups of 192 rows (92 % of the CUs, one round); the WGM = 2 shape (96 rows) does the same for the
-//    half-batch to_q of the cross-attention (M = 22528);
+//  * M = 45056 gives 235 row blocks of 192 rows; tile 34 splits the N tiles of a row block over 512 / 235 = 2 workgroups (470 in
+//    flight, two per CU), M = 22528 over 4;
 //  * epilogues: bias (+ residual) store, GEGLU ([32 h | 32 gate] packed rows, as gemm.hip), q|k store + V^T transposed store -- all
 //    through a wave-private fp32 LDS tile so that every global access is 16 B per lane along the contiguous axis.
 // vmcnt bookkeeping: vector-memory operations of a wave retire from its counter in issue order, loads and stores alike (gfx9 has one
@@ -29,6 +33,9 @@
 // stages, the epilogue STORES issued since the awaited stage (a fixed number per N tile); loads the epilogue issues (bias, residual)
 // are not counted: an uncounted operation can only make a wait longer than necessary, never shorter.  The first version counted ring
 // stages only: every wait that followed an epilogue then also waited for that epilogue's store acknowledgements (~1.5 us per N tile).
+// In the steady state the count depends only on the K-tile index inside the N tile: a compile-time s_waitcnt (wait_stage_const); the
+// run-time form (a switch over immediates: hipcc lowers it to ~35 scalar compares and branches, ~280 cycles per stage) is left to the
+// first and last stages of a launch.
 #include "gemm_args.h"
 
 #include <type_traits>

@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent.parent
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r2_bench_fast_box.json", "r3_bench.json", "r3_bench_fast_box.json", "r3_bench_final_sources.json"])
+@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r2_bench_fast_box.json", "r3_bench.json", "r3_bench_fast_box.json", "r3_bench_final_sources.json", "r3_bench_slow_box.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = (ROOT / "profiles" / name).read_text().strip().splitlines()[-1]
     d = json.loads(line)
