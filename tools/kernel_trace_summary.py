@@ -47,7 +47,7 @@ def main():
     fam = defaultdict(lambda: [0, 0])
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:72s} {c / n:8.1f} {t / c / 1e3:9.2f} {t / n / 1e6:8.3f} {100 * t / busy:6.1f}")
-        key = "gemm_kernel (all instantiations)" if k.startswith("gemm_kernel") else ("flash_attn" if "flash_attn" in k else None)
+        key = "gemm_kernel (all instantiations)" if k.startswith(("gemm_kernel", "rowgemm_kernel")) else ("flash_attn" if "flash_attn" in k else None)
         if key:
             fam[key][0] += c
             fam[key][1] += t
