@@ -7,7 +7,7 @@
 The fp32 oracle (oracle/pipeline.py::stage2_sample over oracle/unet.py) runs the COMPLETE call on the seeded 868.9 M-parameter
 weights (``synth_state_dict(UNetConfig(), seed=0, random_affine=True)`` -- the weights of the other full-size fixtures) and the
 seeded inputs ``synth_inputs(cfg, 32, 64, 1)``; stored: the latents before steps 5 / 10 / 15, the final latents, the guided eps
-of steps 0 / 10 / 19 (fp16).  ~3-5 min on the 8 build-container cores.
+of steps 0 / 10 / 19 (fp16).  80 s on the 8 build-container cores.
 
     python tests/golden/make_fullsize_config0_fixture.py
 """

@@ -14,7 +14,7 @@ Runs the fp32 CPU oracle (oracle/ -- the restatement of /root/reference/src/pipe
   b16_eps   fp16 [8,4,64,88]   guided eps of ONE forward at N = 8 (UNet batch 16; configs[2]'s per-GPU share), step 0
 
 Everything the GPU box needs is in the .npz (weights / inputs are regenerated there from the same seeds with the same
-torch build; the torch version is recorded).  ~10-15 min on the 8 build-container cores.
+torch build; the torch version is recorded).  ~35 min on the 8 build-container cores (475 TFLOP of fp32 at ~0.22 TFLOP/s).
 
     python tests/golden/make_fullsize_config2_fixture.py [--steps 50] [--out tests/golden/fullsize_config2.npz]
 """
