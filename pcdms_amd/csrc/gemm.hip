@@ -731,8 +731,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * silu_f(ag[4 * rg + e] + bg[e]);
                                 } else {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = (ah[4 * rg + e] + bh[e]) * gelu_erf_f(ag[4 * rg + e] + bg[e]);
+                                    const f32x4 hq = {ah[4 * rg], ah[4 * rg + 1], ah[4 * rg + 2], ah[4 * rg + 3]};
+                                    const f32x4 gq = {ag[4 * rg], ag[4 * rg + 1], ag[4 * rg + 2], ag[4 * rg + 3]};
+                                    v = geglu_quad(hq + bh, gq + bg);
                                 }
                                 *(f32x4*)(ep + (jj * F + prow) * EPW + nl) = v;
                             }

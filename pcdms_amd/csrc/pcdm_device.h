@@ -154,15 +154,43 @@ __device__ __forceinline__ float fast_rcp(float x) {
 #endif
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf-based GELU (PyTorch F.gelu default, diffusers GEGLU)
-// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 rounding of the result): one v_exp,
-// one v_rcp and a 5-term Horner -- ~3x fewer instructions than libm erff, which dominated the GEGLU epilogue.
+// erf-based GELU (PyTorch F.gelu default, diffusers GEGLU):  gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|).
+// Phi(-t) = 2^Q(t) with Q a degree-5 minimax fit of log2(Phi(-t)) on [0, 6] (weighted by t Phi(-t), i.e. minimising the ABSOLUTE error
+// of the result; tools/fit_gelu.py derives and checks the coefficients); |x| is clamped to 6, where the term is 6e-9.
+// |gelu_erf_f(x) - gelu(x)| <= 7e-7 for every x (fp32 evaluation included), <= 2^-11 relative wherever |gelu(x)| >= 2e-3 -- a quarter of
+// the bf16 half-ulp of the result.  ONE transcendental (v_exp_f32) and FMAs: the Abramowitz-Stegun 7.1.26 form it replaces (v_rcp +
+// v_exp + 5-term Horner + sign select, same absolute error) was 40 % of the level-0 GEGLU launch (profiles/r3_rowgemm_anatomy.txt);
+// quarter-rate instructions cost four issue slots each.  The two-wide form lets hipcc emit v_pk_fma_f32 / v_pk_mul_f32 (two lanes'
+// worth of fp32 per issue slot) for the polynomial.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PCDM_GELU_Q0 (-1.000037670135498f)
+#define PCDM_GELU_Q1 (-1.1507878303527832f)
+#define PCDM_GELU_Q2 (-0.4599924385547638f)
+#define PCDM_GELU_Q3 (-0.051827382296323776f)
+#define PCDM_GELU_Q4 (0.007084557320922613f)
+#define PCDM_GELU_Q5 (-0.0004733092791866511f)
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = fast_rcp(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * fast_exp2(-1.44269504088896341f * z * z);   // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
+    const float t = fminf(fabsf(x), 6.0f);
+    const float q = PCDM_GELU_Q0 + t * (PCDM_GELU_Q1 + t * (PCDM_GELU_Q2 + t * (PCDM_GELU_Q3 + t * (PCDM_GELU_Q4 + t * PCDM_GELU_Q5))));
+    return fmaxf(x, 0.f) - t * fast_exp2(q);
+}
+__device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
+    const f32x2 t = {fminf(fabsf(x[0]), 6.0f), fminf(fabsf(x[1]), 6.0f)};
+    f32x2 q = t * PCDM_GELU_Q5 + PCDM_GELU_Q4;
+    q = q * t + PCDM_GELU_Q3;
+    q = q * t + PCDM_GELU_Q2;
+    q = q * t + PCDM_GELU_Q1;
+    q = q * t + PCDM_GELU_Q0;
+    const f32x2 e = {fast_exp2(q[0]), fast_exp2(q[1])};
+    const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return r - t * e;
+}
+// v[e] = h[e] * gelu(g[e]), e = 0..3 (one accumulator quad of the GEGLU epilogues)
+__device__ __forceinline__ f32x4 geglu_quad(f32x4 h, f32x4 g) {
+    const f32x2 a = gelu_erf_f2(f32x2{g[0], g[1]}), b = gelu_erf_f2(f32x2{g[2], g[3]});
+    const f32x2 ha = {h[0], h[1]}, hb = {h[2], h[3]};
+    const f32x2 va = ha * a, vb = hb * b;
+    return f32x4{va[0], va[1], vb[0], vb[1]};
 }
 
 // ---- MFMA (cdna_hip_programming.md §3 fragment maps) -----------------------------------------

@@ -295,8 +295,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, WGM* WGN == 4 ? 2 : 1) void rowgemm_
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = ah[e] * silu_f(ag[e]);
                         } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ah[e] * gelu_erf_f(ag[e]);
+                            v = geglu_quad(ah, ag);
                         }
                         *(f32x4*)(ep + lrow * EPW + i * 16 + 4 * lq) = v;
                     }

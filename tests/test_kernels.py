@@ -714,3 +714,51 @@ def test_rowgemm_thin_k(backend):
     pw64 = ops.pack_linear(rnd(64, 64, seed=1).float(), None, dev)
     with pytest.raises(RuntimeError):
         ops.gemm(rnd(32, 64, seed=2).to(dev), pw64, torch.empty(32, 64, dtype=BF16, device=dev), tile=31)
+
+
+def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32)
+    v = bits.to(torch.int16).view(BF16)
+    v = v[torch.isfinite(v.float()) & (v.float() >= lo) & (v.float() <= hi)]
+    return v[::stride].contiguous()
+
+
+def test_gelu_accuracy(backend):
+    """The kernels' erf-GELU (pcdm_device.h ``gelu_erf_f`` / ``gelu_erf_f2``: max(x, 0) - |x| 2^Q(|x|), Q a degree-5 fit of
+    log2 Phi(-t); tools/fit_gelu.py) against ``F.gelu`` in fp64 on EVERY bf16 value in [-9, 9]: |err| <= 1e-6 absolute, <= 2^-11
+    relative wherever |gelu(x)| >= 2e-3 (VERDICT r3 #5 asked for the bound to be stated and tested).  Scalar form: pcdm_gemm's generic
+    epilogue with act = GELU, identity weights, fp32 output.  Two-wide form: the GEGLU epilogues of gemm.hip and rowgemm.hip with
+    h = 1 (zero weights, bias 1) -- bf16 output, so the bound there adds the result's own rounding (2^-8 relative)."""
+    dev = backend.device
+    x = _all_bf16_in(-9.0, 9.0, stride=23 if backend.is_emu else 1)
+    exact = F.gelu(x.double())
+    # ---- scalar form, fp32 out
+    K = N = 64
+    M = (x.numel() + K - 1) // K
+    xp = torch.zeros(M * K, dtype=BF16)
+    xp[: x.numel()] = x
+    a = xp.view(M, K)
+    pw = ops.pack_linear(torch.eye(N, K), None, dev)
+    out = torch.empty(1, N, M, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), pw, out, rows_per_batch=M, epilogue=ops.EPI_NCHW_F32, act=ops.ACT_GELU, tile=2)
+    backend.sync()
+    got = out[0].t().reshape(-1)[: x.numel()].double().cpu()
+    err = (got - exact).abs()
+    assert err.max().item() <= 1e-6, err.max().item()
+    big = exact.abs() >= 2e-3
+    assert (err[big] / exact[big].abs()).max().item() <= 2.0 ** -11
+    # ---- two-wide form through the GEGLU epilogues (tiled kernel: K = 64; A-in-registers kernel: K = 320)
+    for (Kg, tile) in ((64, 4), (320, 34)):
+        D = Kg
+        Mg = (x.numel() + D - 1) // D
+        xg = torch.zeros(Mg * D, dtype=BF16)
+        xg[: x.numel()] = x
+        w = torch.cat([torch.zeros(D, Kg), torch.eye(D, Kg)], 0)            # rows [h | gate]: h = bias = 1, gate = x
+        bias = torch.cat([torch.ones(D), torch.zeros(D)])
+        pg = ops.pack_geglu(w, bias, dev)
+        og = torch.empty(Mg, D, dtype=BF16, device=dev)
+        ops.gemm(xg.view(Mg, D).to(dev), pg, og, epilogue=ops.EPI_GEGLU, tile=tile)
+        backend.sync()
+        gg = og.reshape(-1)[: x.numel()].double().cpu()
+        # bf16 output: the exact value's own rounding (half an ulp <= 2^-8 relative) + the 1e-6 of the approximation
+        assert ((gg - exact).abs() <= 2.0 ** -8 * exact.abs() + 1e-6).all(), (Kg, tile, (gg - exact).abs().max().item())
