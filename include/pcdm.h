@@ -42,6 +42,26 @@ int pcdm_groupnorm_cluster_timeouts(const float* ws, unsigned* count_out, pcdm_s
 int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
                    const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
 
+/* GroupNorm whose FIRST source is the not-yet-reduced output of a split-K pcdm_gemm (defer_reduce = 1):
+ *   x1[m, n] = bf16( sum_s part[s][m][n] + bias[n] + rowvec[m / HW][n] + residual[m][n] ),  m < M = B * HW, n < N  (= C1)
+ * -- the arithmetic (and summation order) of the reduce kernel pcdm_gemm would have launched: results are bit-identical to
+ * pcdm_gemm(defer_reduce = 0) + pcdm_groupnorm.  x2 / C2: the second (plain bf16) source of the virtual concat, as pcdm_groupnorm.
+ * pre_out [M, N] bf16 must always be provided; it is WRITTEN (the reduced pre-norm tensor, for the residual / skip connections
+ * that read it later) iff store_pre != 0 -- except on the two-launch path of very large slabs, which writes it regardless. */
+typedef struct pcdm_gn_splitk_src {
+    const float* part;     /* pcdm_gemm_params.ws of the producing call */
+    int32_t split_k, M, N, Npad;
+    const float* bias;     /* [Npad] or NULL */
+    const float* rowvec;   /* fp32 [B, ldrv] or NULL (rows_per_batch of the producing call must be HW) */
+    int64_t ldrv;
+    const void* residual;  /* bf16 [M, ldr] or NULL (res_mod = M) */
+    int64_t ldr;
+    void* pre_out;
+    int32_t store_pre;
+} pcdm_gn_splitk_src;
+int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* src, const void* x2, int C2, int B, int HW, int groups, float eps,
+                          const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
+
 /* ---- K8 LayerNorm  [BasicTransformerBlock.norm1/2/3, diffusers attention.py]  x,y [rows,C] bf16 */
 int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma, const float* beta,
                    pcdm_stream_t s);
@@ -103,7 +123,14 @@ typedef struct pcdm_gemm_params {
                               K7 / K11) -- and ln_wsum[n] = sum_k W'[n, k] (fp32 [Npad], of the bf16 values).  The kernel takes each A row's mean / rstd
                               (eps ln_eps) and returns rstd (acc - mean ln_wsum[n]) + bias'[n] = LayerNorm(A) W^T + bias.  Other tiles return -1 when set */
     float ln_eps;
+    int32_t defer_reduce;  /* split_k > 1 only: leave the split_k fp32 partial slabs in ws ([split_k][M][Npad]) and do NOT launch the reduce
+                              kernel: out is not written; bias / rowvec / residual are not applied.  The consumer applies them:
+                              pcdm_groupnorm_splitk (the GroupNorm that follows every split-K convolution of the UNet: conv1 -> norm2, conv2 ->
+                              the next block's norm) reads the slabs, so the reduce launch, its bf16 write and the norm's read of it disappear.
+                              ws must stay untouched until that consumer has run (same stream). */
 } pcdm_gemm_params;
+/* pcdm_version() == 2: the struct above ends with defer_reduce (1: ended with ln_eps).  Zero-initialise it (memset) and build against
+ * the header of the library in use: a host compiled against an older header passes a shorter struct. */
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 
 /* ---- K9/K10 fused attention (replaces xformers.ops.memory_efficient_attention enabled at

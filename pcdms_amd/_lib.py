@@ -40,8 +40,16 @@ class GemmParams(C.Structure):
         ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32), ("act", C.c_int32),
         ("zero_rows", C.c_int32),
-        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
     ]
+
+
+class GnSplitKSrc(C.Structure):
+    """Mirror of ``pcdm_gn_splitk_src`` (include/pcdm.h)."""
+
+    _fields_ = [("part", C.c_void_p), ("split_k", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32),
+                ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ldrv", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
+                ("pre_out", C.c_void_p), ("store_pre", C.c_int32)]
 
 
 class UNetConfig(C.Structure):
@@ -60,6 +68,7 @@ _SIGS = {
     "pcdm_groupnorm_ws_floats": ([_I, _I], _L),
     "pcdm_groupnorm_cluster_timeouts": ([_P, C.POINTER(C.c_uint), _P], C.c_int),
     "pcdm_groupnorm": ([_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
+    "pcdm_groupnorm_splitk": ([C.POINTER(GnSplitKSrc), _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_layernorm": ([_P, _P, _I, _I, _F, _P, _P, _P], C.c_int),
     "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),
     "pcdm_flash_attn": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),

@@ -20,8 +20,9 @@
 //    buffer stores (no predicates); V^T of the fused q|k|v projection written transposed.  Split-K partials go to an fp32 workspace.
 //  * Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous run of M-tiles and
 //    walks all N-tiles of an A tile back to back (cdna_hip_programming.md T1, bijective form).
-//  * What bounds it: with real operands the MFMA + LDS loop without any global loads sustains 1.1-1.5 PF/s (power), and
-//    a CU fills its LDS from L2 at 23-37 B per cycle; the 192x320 tile (120 FLOP per staged byte) sits at both limits at once.
+//  * What bounds it: with real operands the MFMA + LDS loop without any global loads sustains 1.1-1.5 PF/s (power).  The
+//    L2 -> LDS fill path is NOT the limiter (profiles/r3_pmc_fill.json: TA busy 2-6 %, TCC busy 7-11 % on every UNet shape); the thin-K
+//    launches are bounded by their prologue / epilogue around a five-tile K loop and by one barrier domain per CU (tools/gemm_anatomy.py).
 #include "gemm_args.h"
 
 #include <type_traits>
@@ -931,7 +932,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB>), dim3(g.tiles_m * g.tiles_n * g.split_k),
                 dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
-    if (g.split_k > 1) {
+    if (g.split_k > 1 && !g.defer_reduce) {
         const int64_t n = (int64_t)g.M * (g.N / 4);
         PCDM_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
         PCDM_CHECK_LAUNCH();
@@ -1045,6 +1046,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.ln_wsum = p->ln_wsum;
     a.ln_eps = p->ln_eps;
     a.split_k = p->split_k > 1 ? p->split_k : 1;
+    a.defer_reduce = (p->defer_reduce && a.split_k > 1) ? 1 : 0;
+    if (a.defer_reduce && (p->act || p->res_mod > 0 && p->res_mod < p->M)) return -1;   // (the consumer applies bias / rowvec / residual only)
     a.ws = p->ws;
     if (a.split_k > 1) {
         if (p->epilogue != PCDM_EPI_STORE || !p->ws || a.split_k > p->K / BK || a.split_k > 64) return -1;

@@ -41,6 +41,82 @@ __device__ __forceinline__ u16x8 gn_load(const u16* x1, int C1, const u16* x2, i
     return *(const u16x8*)p;
 }
 
+// The input of the single-pass kernels: the virtual concat x1 | x2 of two bf16 tensors -- or, for x1, the tensor a split-K GEMM has NOT
+// yet reduced (pcdm_gemm_params.defer_reduce): x1[row, c] = bf16( sum_s part[s][row][c] + bias[c] + rowvec[b][c] + residual[row][c] ),
+// the arithmetic of gemm.hip's splitk_reduce_kernel in the same order (bit-identical to reduce-then-normalise).  A single-pass
+// kernel loads every element of its slab exactly once, so it can be the reduce kernel as well: one launch, one pass over the
+// partial sums, and the bf16 tensor is written (pre_out) only when something else reads it (a residual / skip connection).
+struct GnSrc {
+    const u16* x1;
+    int C1;
+    const u16* x2;
+    int C2;
+    const float* part;      // split-K form of x1: [S][M][ldp] fp32 partial sums (x1 is unused then)
+    int S;
+    int64_t slab;           // M * ldp
+    int ldp;
+    const float* bias;      // [>= C1] or NULL
+    const float* rowvec;    // [B][ldrv] or NULL (the time-embedding projection row of the batch entry)
+    int ldrv;
+    const u16* residual;    // [M][ldr] or NULL
+    int ldr;
+    u16* pre_out;           // [M][C1] or NULL: the reduced tensor
+};
+
+__device__ __attribute__((aligned(32))) const unsigned int g_gn_zero32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <bool SK>
+__device__ __forceinline__ u16x8 gn_src_load(const GnSrc& s, int b, int64_t row, int c) {
+    if (!SK || c >= s.C1) return gn_load(s.x1, s.C1, s.x2, s.C2, row, c);
+    // operands first (unconditional loads; absent ones read zeros), then the slabs in their fixed order, four in flight at a time
+    const f32x4 b0 = *(const f32x4*)(s.bias ? s.bias + c : (const float*)g_gn_zero32);
+    const f32x4 b1 = *(const f32x4*)(s.bias ? s.bias + c + 4 : (const float*)g_gn_zero32);
+    const f32x4 t0 = *(const f32x4*)(s.rowvec ? s.rowvec + (int64_t)b * s.ldrv + c : (const float*)g_gn_zero32);
+    const f32x4 t1 = *(const f32x4*)(s.rowvec ? s.rowvec + (int64_t)b * s.ldrv + c + 4 : (const float*)g_gn_zero32);
+    const u16x8 rv = *(const u16x8*)(s.residual ? s.residual + row * s.ldr + c : (const u16*)g_gn_zero32);
+    const float* wp = s.part + row * s.ldp + c;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    int k = 0;
+    for (; k + 4 <= s.S; k += 4) {
+        f32x4 a[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *(const f32x4*)(wp + (k + u) * s.slab);
+            d[u] = *(const f32x4*)(wp + (k + u) * s.slab + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v0 += a[u];
+            v1 += d[u];
+        }
+    }
+    for (; k < s.S; ++k) {
+        v0 += *(const f32x4*)(wp + k * s.slab);
+        v1 += *(const f32x4*)(wp + k * s.slab + 4);
+    }
+    v0 += b0;
+    v1 += b1;
+    v0 += t0;
+    v1 += t1;
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = f2bf(v0[e] + bf2f(rv[e]));
+        o[e + 4] = f2bf(v1[e] + bf2f(rv[e + 4]));
+    }
+    return o;
+}
+
+// the reduce alone (one thread per octet), for shapes that take the two-kernel GroupNorm path
+__global__ __launch_bounds__(kThreads) void gn_reduce_kernel(const GnSrc s, int HW, int64_t rows) {
+    const int noct = s.C1 / 8;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= rows * noct) return;
+    const int64_t row = i / noct;
+    const int c = (int)(i - row * noct) * 8;
+    *(u16x8*)(s.pre_out + row * s.C1 + c) = gn_src_load<true>(s, (int)(row / HW), row, c);
+}
+
 // part: [B][nchunk][groups][2]  per-(row-chunk, group) partial {sum, sum of squares}, fixed summation order
 __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restrict__ x1, int C1,
                                                           const u16* __restrict__ x2, int C2, int HW,
@@ -234,13 +310,12 @@ __device__ __forceinline__ void gn_block_sum4(float (&x)[4], int n /* live entri
 #define GN_KEEP_PACKED(v) asm volatile("" : "+v"(v))
 #endif
 
-template <int THREADS, int MAXR>
-__global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict__ x1, int C1, const u16* __restrict__ x2,
-                                                          int C2, int B, int HW, int gs, int gpb, int noct, float eps,
+template <int THREADS, int MAXR, bool SK>
+__global__ __launch_bounds__(THREADS) void gn_fused_kernel(const GnSrc src, int B, int HW, int gs, int gpb, int noct, float eps,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int fuse_silu, u16* __restrict__ y) {
     __shared__ float red[(THREADS / 64) * 4];
-    const int C = C1 + C2;
+    const int C = src.C1 + src.C2;
     const int b = blockIdx.x % B, gset = blockIdx.x / B;
     const int t = threadIdx.x;
     const int rows_par = THREADS / noct;
@@ -256,7 +331,14 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict
     for (int i = 0; i < MAXR; ++i) {
         const int r = rp + i * rows_par;
         const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        v[i] = (active && r < HW) ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, c) : z;
+        v[i] = (active && r < HW) ? gn_src_load<SK>(src, b, (int64_t)b * HW + r, c) : z;
+    }
+    if (SK && src.pre_out && active && c < src.C1) {   // the reduced tensor, for the residual / skip connections that read it later
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int r = rp + i * rows_par;
+            if (r < HW) *(u16x8*)(src.pre_out + ((int64_t)b * HW + r) * src.C1 + c) = v[i];
+        }
     }
     // ---- mean
     float s[8];
@@ -333,8 +415,8 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const u16* __restrict
 // in two launches.  The grid is at most one workgroup per CU, so all S partners are resident (no deadlock); the counters are
 // self-resetting (the last workgroup to have READ the partials clears them; the next launch cannot start before this one ends).
 // ws layout: [slab][S][4 groups][2] floats, then [slab][2] unsigned counters (arrived, read) -- zeroed once by the caller.
-template <int THREADS, int MAXR>
-__global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restrict__ x1, int C1, const u16* __restrict__ x2, int C2, int B,
+template <int THREADS, int MAXR, bool SK>
+__global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, int B,
                                                             int HW, int gs, int gpb, int noct, int S, int rows_per_chunk, float eps,
                                                             double inv_n /* 1 / (HW * gs) */, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int fuse_silu, u16* __restrict__ y,
@@ -342,7 +424,7 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     __shared__ float red[(THREADS / 64) * 4];
     __shared__ float stat[8];                    // {mean, rstd} of the <= 4 groups of this slab
     __shared__ int stat_flag[1];                 // 1: the partners did not arrive in time (see the poll)
-    const int C = C1 + C2;
+    const int C = src.C1 + src.C2;
     const int nslab = gridDim.x / S;
     const int slab = blockIdx.x % nslab, chunk = blockIdx.x / nslab;   // partners are nslab apart: different XCDs do not matter here
     const int b = slab % B, gset = slab / B;
@@ -362,7 +444,14 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     for (int i = 0; i < MAXR; ++i) {
         const int r = r0 + rp + i * rows_par;
         const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        v[i] = (active && r < r1) ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, c) : z;
+        v[i] = (active && r < r1) ? gn_src_load<SK>(src, b, (int64_t)b * HW + r, c) : z;
+    }
+    if (SK && src.pre_out && active && c < src.C1) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int r = r0 + rp + i * rows_par;
+            if (r < r1) *(u16x8*)(src.pre_out + ((int64_t)b * HW + r) * src.C1 + c) = v[i];
+        }
     }
     // ---- this chunk's per-group sum and sum of squares (rows beyond the chunk hold zeros)
     // (two passes over the packed registers: sums, then sums of squares -- holding both sets of accumulators and the slab
@@ -432,7 +521,7 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
     if (alone) {
         for (int r = rp; r < HW && active; r += rows_par) {
-            const u16x8 z = gn_load(x1, C1, x2, C2, (int64_t)b * HW + r, c);
+            const u16x8 z = gn_src_load<SK>(src, b, (int64_t)b * HW + r, c);   // (split-K source: recomputed, same value)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = bf2f(z[e]);
@@ -495,10 +584,14 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const u16* __restri
 }
 
 template <int THREADS, int MAXR>
-void launch_gn_fused(hipStream_t st, const u16* x1, int C1, const u16* x2, int C2, int B, int HW, int groups, int gs, int gpb,
+void launch_gn_fused(hipStream_t st, const GnSrc& src, int B, int HW, int groups, int gs, int gpb,
                      int noct, float eps, const float* gamma, const float* beta, int silu, u16* y) {
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_fused_kernel<THREADS, MAXR>), dim3((groups / gpb) * B), dim3(THREADS), 0, st, x1, C1, x2, C2, B,
-                HW, gs, gpb, noct, eps, gamma, beta, silu, y);
+    if (src.part)
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_fused_kernel<THREADS, MAXR, true>), dim3((groups / gpb) * B), dim3(THREADS), 0, st, src, B,
+                    HW, gs, gpb, noct, eps, gamma, beta, silu, y);
+    else
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_fused_kernel<THREADS, MAXR, false>), dim3((groups / gpb) * B), dim3(THREADS), 0, st, src, B,
+                    HW, gs, gpb, noct, eps, gamma, beta, silu, y);
 }
 
 // One wave per row; up to NO octets per lane (NO = 3: C <= 1536, the UNet's widths; NO = 8: C <= 4096, the stage-1 prior's
@@ -653,9 +746,14 @@ static bool gn_cluster_enabled() {
             if (getenv(m)) ok = false;
         int cus = 0, nb8 = 0, nb16 = 0;
         if (ok && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ok = false;
-        if (ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, gn_cluster_kernel<512, 8>, 512, 0) != hipSuccess ||
-                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, gn_cluster_kernel<512, 16>, 512, 0) != hipSuccess))
+        int nb8s = 0, nb16s = 0;
+        if (ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, gn_cluster_kernel<512, 8, false>, 512, 0) != hipSuccess ||
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, gn_cluster_kernel<512, 16, false>, 512, 0) != hipSuccess ||
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8s, gn_cluster_kernel<512, 8, true>, 512, 0) != hipSuccess ||
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16s, gn_cluster_kernel<512, 16, true>, 512, 0) != hipSuccess))
             ok = false;
+        nb8 = nb8 < nb8s ? nb8 : nb8s;
+        nb16 = nb16 < nb16s ? nb16 : nb16s;
         if (ok && ((int64_t)cus * (nb8 < nb16 ? nb8 : nb16) < kGnClusterMaxWgs || cus < kGnClusterMaxWgs)) ok = false;
         state[dev] = ok ? 1 : 2;
     }
@@ -701,13 +799,11 @@ extern "C" int pcdm_groupnorm_cluster_timeouts(const float* ws, unsigned* count_
 #endif
 }
 
-extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
-                              const float* gamma, const float* beta, int fuse_silu, void* y, float* ws,
-                              pcdm_stream_t s) {
-    const int C = C1 + C2;
-    if (!x1 || !y || !ws || B <= 0 || HW <= 0 || groups <= 0 || groups > 256) return -1;
-    if (C1 % 8 || C2 % 8 || C % groups || C > kGnMaxC || (C2 > 0 && !x2)) return -1;
-    hipStream_t st = (hipStream_t)s;
+// GroupNorm of `src` (plain or split-K form); the split-K form takes the single-pass paths as it is and the two-kernel path behind a
+// reduce launch of its own (into src.pre_out, which the caller always provides)
+static int gn_launch(GnSrc src, int B, int HW, int groups, float eps, const float* gamma, const float* beta, int fuse_silu, void* y,
+                     float* ws, hipStream_t st, u16* reduce_buf = nullptr /* split-K form: [M][C1] for the two-kernel path */) {
+    const int C1 = src.C1, C2 = src.C2, C = C1 + C2;
     {   // single-pass path: the (batch, group set) slab in registers
         const int gs = C / groups;
         int gpb = 1;
@@ -725,9 +821,8 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
         if (gpb <= 4 && groups % gpb == 0 && noct <= 64 && (int64_t)HW * noct * 16 <= max_slab && !to_cluster) {
             // rows per thread at 256 / 512 / 1024 threads, at most 8 (all loads of the slab in flight at once, <= 128 KiB)
             auto need = [&](int th) { return (HW + th / noct - 1) / (th / noct); };
-            const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
             bool done = true;
-#define GN_FUSED(TH, MR) launch_gn_fused<TH, MR>(st, a1, C1, a2, C2, B, HW, groups, gs, gpb, noct, eps, gamma, beta, fuse_silu, (u16*)y)
+#define GN_FUSED(TH, MR) launch_gn_fused<TH, MR>(st, src, B, HW, groups, gs, gpb, noct, eps, gamma, beta, fuse_silu, (u16*)y)
             if (need(256) <= 8) GN_FUSED(256, 8);
             else if (need(512) <= 8) GN_FUSED(512, 8);
             else if (need(1024) <= 8) GN_FUSED(1024, 8);
@@ -753,31 +848,68 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
                 const int rpc = (HW + S - 1) / S;
                 const int need = (rpc + rows_par - 1) / rows_par;
                 float* cws = ws;   // cluster area at the head of the workspace: [kGnClusterMaxWgs][8] partials, then the counters
-                const u16 *a1 = (const u16*)x1, *a2 = (const u16*)x2;
                 const double inv_n = 1.0 / ((double)HW * gs);
-                if (need <= 8)
-                    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, 8>), dim3(nslab * S), dim3(512), 0, st, a1, C1, a2, C2, B, HW, gs, gpb,
-                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, cws);
-                else
-                    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, 16>), dim3(nslab * S), dim3(512), 0, st, a1, C1, a2, C2, B, HW, gs, gpb,
-                                noct, S, rpc, eps, inv_n, gamma, beta, fuse_silu, (u16*)y, cws);
+#define GN_CLUSTER(MR, SK_)                                                                                                              \
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_cluster_kernel<512, MR, SK_>), dim3(nslab * S), dim3(512), 0, st, src, B, HW, gs, gpb, noct, S, rpc, eps, \
+                inv_n, gamma, beta, fuse_silu, (u16*)y, cws)
+                if (need <= 8) {
+                    if (src.part) GN_CLUSTER(8, true);
+                    else GN_CLUSTER(8, false);
+                } else {
+                    if (src.part) GN_CLUSTER(16, true);
+                    else GN_CLUSTER(16, false);
+                }
+#undef GN_CLUSTER
                 PCDM_CHECK_LAUNCH();
                 return 0;
             }
         }
     }
 #endif
+    if (src.part) {   // two-kernel path: reduce first (one launch more, as before the fusion), then the plain tensor
+        const int64_t rows = (int64_t)B * HW, n = rows * (C1 / 8);
+        src.pre_out = reduce_buf;
+        PCDM_LAUNCH(gn_reduce_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, src, HW, rows);
+        PCDM_CHECK_LAUNCH();
+        src.x1 = src.pre_out;
+        src.part = nullptr;
+    }
     const GnGeom g = gn_geom(C);
     const int nchunk = gn_chunks(HW, g.rows_par);
     const int rpc = (HW + nchunk - 1) / nchunk;
     ws += kGnClusterFloats;   // (the head belongs to the cluster kernel)
-    PCDM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, (const u16*)x1, C1, (const u16*)x2, C2, HW,
-                rpc, groups, ws);
+    PCDM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, src.x1, C1, src.x2, C2, HW, rpc, groups, ws);
     PCDM_CHECK_LAUNCH();
-    PCDM_LAUNCH(gn_apply_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, (const u16*)x1, C1, (const u16*)x2, C2, HW,
-                rpc, groups, eps, (const float*)ws, gamma, beta, fuse_silu, (u16*)y);
+    PCDM_LAUNCH(gn_apply_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, src.x1, C1, src.x2, C2, HW, rpc, groups, eps, (const float*)ws, gamma,
+                beta, fuse_silu, (u16*)y);
     PCDM_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
+                              const float* gamma, const float* beta, int fuse_silu, void* y, float* ws,
+                              pcdm_stream_t s) {
+    const int C = C1 + C2;
+    if (!x1 || !y || !ws || B <= 0 || HW <= 0 || groups <= 0 || groups > 256) return -1;
+    if (C1 % 8 || C2 % 8 || C % groups || C > kGnMaxC || (C2 > 0 && !x2)) return -1;
+    GnSrc src{};
+    src.x1 = (const u16*)x1; src.C1 = C1; src.x2 = (const u16*)x2; src.C2 = C2;
+    return gn_launch(src, B, HW, groups, eps, gamma, beta, fuse_silu, y, ws, (hipStream_t)s);
+}
+
+extern "C" int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* p, const void* x2, int C2, int B, int HW, int groups, float eps,
+                                     const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s) {
+    if (!p || !p->part || !p->pre_out || !y || !ws || B <= 0 || HW <= 0 || groups <= 0 || groups > 256) return -1;
+    const int C1 = p->N, C = C1 + C2;
+    if (C1 <= 0 || C1 % 8 || C2 % 8 || C % groups || C > kGnMaxC || (C2 > 0 && !x2)) return -1;
+    if (p->split_k < 2 || p->split_k > 64 || p->Npad < C1 || p->Npad % 8 || p->M != B * HW) return -1;
+    if ((p->rowvec && (p->ldrv % 4 || ((uintptr_t)p->rowvec & 15))) || (p->residual && (p->ldr < C1 || p->ldr % 8))) return -1;
+    GnSrc src{};
+    src.x1 = (const u16*)p->pre_out; src.C1 = C1; src.x2 = (const u16*)x2; src.C2 = C2;
+    src.part = p->part; src.S = p->split_k; src.ldp = p->Npad; src.slab = (int64_t)p->M * p->Npad;
+    src.bias = p->bias; src.rowvec = p->rowvec; src.ldrv = (int)p->ldrv; src.residual = (const u16*)p->residual; src.ldr = (int)p->ldr;
+    src.pre_out = p->store_pre ? (u16*)p->pre_out : nullptr;   // (the two-kernel path writes the buffer whatever the flag)
+    return gn_launch(src, B, HW, groups, eps, gamma, beta, fuse_silu, y, ws, (hipStream_t)s, (u16*)p->pre_out);
 }
 
 extern "C" int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma,

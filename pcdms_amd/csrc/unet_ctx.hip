@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -55,6 +56,10 @@ constexpr int64_t kAlign = 256;
 constexpr int64_t kSplitKFloats = 1 << 24;   // split-K workspace (fp32), as pcdms_amd.ops._splitk_ws
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+bool getenv_off(const char* name) {   // A/B switches shared with pcdms_amd.ops ("0" = off)
+    const char* e = getenv(name);
+    return e && e[0] == '0';
+}
 
 struct Planner {
     pcdm_unet* u;
@@ -167,7 +172,11 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         int64_t ldo = 0;   // 0: N (GEGLU / NCHW: N)
         const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles only)
         float ln_eps = 0.f;
+        int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
     };
+    // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
+    pcdm_gn_splitk_src pend;
+    const void* pend_out = nullptr;
     // out = epilogue(A W^T): the parameter block pcdms_amd.ops.gemm builds, the tile from the registered table (0 = library heuristic)
     void gemm(const void* a, int64_t lda, int M, const PW* w, void* out, const G& g) {
         if (rc || !w) return;
@@ -210,6 +219,17 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
                 if ((int64_t)p.split_k * M * w->Npad > kSplitKFloats) { p.split_k = 0; p.tile = 0; p.ws = nullptr; p.ws_floats = 0; }
             }
         }
+        if (pend_out) { rc = -1; u->err = "a deferred split-K reduce was never consumed"; return; }
+        if (g.defer && p.split_k > 1 && g.epilogue == PCDM_EPI_STORE && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0) &&
+            !getenv_off("PCDM_DEFER_SPLITK")) {
+            p.defer_reduce = 1;
+            memset(&pend, 0, sizeof(pend));
+            pend.part = p.ws; pend.split_k = p.split_k; pend.M = M; pend.N = w->N; pend.Npad = w->Npad;
+            pend.bias = p.bias; pend.rowvec = p.rowvec; pend.ldrv = g.rowvec ? (g.ldrv ? g.ldrv : w->N) : 0;
+            pend.residual = p.residual; pend.ldr = p.ldr;
+            pend.pre_out = out; pend.store_pre = g.defer == 1;
+            pend_out = out;
+        }
         chk(pcdm_gemm(&p, st), "pcdm_gemm");
     }
     // LayerNorm -> GEMM: the folded form on the A-in-registers kernel when the table says so, two launches otherwise
@@ -239,6 +259,12 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
     }
     void groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, float eps, const float* gamma, const float* beta, int silu, void* y) {
         if (rc) return;
+        if (pend_out) {
+            if (pend_out != x1 || pend.N != C1) { rc = -1; u->err = "deferred split-K reduce: the next GroupNorm reads another tensor"; return; }
+            pend_out = nullptr;
+            chk(pcdm_groupnorm_splitk(&pend, x2, C2, B, HW, u->cfg.norm_groups, eps, gamma, beta, silu, y, buf<float>("gnws"), st), "pcdm_groupnorm_splitk");
+            return;
+        }
         chk(pcdm_groupnorm(x1, C1, x2, C2, B, HW, u->cfg.norm_groups, eps, gamma, beta, silu, y, buf<float>("gnws"), st), "pcdm_groupnorm");
     }
 };
@@ -473,7 +499,8 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     }
     const float* temb = R.buf<float>("temb");
 
-    auto resnet = [&](const std::string& p, const void* x1, int C1, const void* x2, int C2, int HW_, int hh, int ww, const std::string& out_name) -> void* {
+    auto resnet = [&](const std::string& p, const void* x1, int C1, const void* x2, int C2, int HW_, int hh, int ww, const std::string& out_name,
+                      bool gn_next) -> void* {   // gn_next: the next reader of the block's output is a GroupNorm (split-K reduce folded into it)
         const PW *cv1 = R.pw(p + "conv1"), *cv2 = R.pw(p + "conv2");
         if (R.rc) return nullptr;
         const int cin = C1 + C2, cout = cv1->N, M = B * HW_;
@@ -481,6 +508,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         Run::G g;
         g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = hh; g.Wo = ww;
         g.rowvec = temb + toff.at(p); g.ldrv = temb_n; g.rows_per_batch = HW_;
+        g.defer = 2;
         R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
         R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
         const void* res = x1;
@@ -493,6 +521,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         Run::G g2;
         g2.conv = 1; g2.B = B; g2.Hi = hh; g2.Wi = ww; g2.Ho = hh; g2.Wo = ww;
         g2.residual = res; g2.ldr = cout; g2.res_mod = M;
+        g2.defer = gn_next ? 1 : 0;
         void* out = R.buf(out_name);
         R.gemm(R.buf("gn"), cout, M, cv2, out, g2);
         return out;
@@ -574,10 +603,10 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         for (int j = 0; j < Lb; ++j) {
             const std::string nm = "d" + std::to_string(i) + "." + std::to_string(j), rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".";
             if (has_cross(c, i)) {
-                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r");
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r", true);
                 x = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, ci, c.heads[i], hh * ww, nm);
             } else {
-                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm);
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm, j < Lb - 1 || i == n - 1);
             }
             skips.push_back({x, hh, ww, ci});
         }
@@ -585,6 +614,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             const int ho = (hh - 1) / 2 + 1, wo = (ww - 1) / 2 + 1;
             Run::G g;
             g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = ho; g.Wo = wo; g.stride = 2;
+            g.defer = 1;   // -> the next block's norm1
             void* o = R.buf("ds" + std::to_string(i));
             R.gemm(x, 0, B * ho * wo, R.pw("down_blocks." + std::to_string(i) + ".downsamplers.0.conv"), o, g);
             x = o;
@@ -594,9 +624,9 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     }
     // ---- 4. mid (ref :775-783)
     const int cm = c.block_out_channels[n - 1];
-    x = resnet("mid_block.resnets.0.", x, cm, nullptr, 0, hh * ww, hh, ww, "r");
+    x = resnet("mid_block.resnets.0.", x, cm, nullptr, 0, hh * ww, hh, ww, "r", true);
     x = transformer("mid_block.attentions.0.", x, cm, c.heads[n - 1], hh * ww, "r2");
-    x = resnet("mid_block.resnets.1.", x, cm, nullptr, 0, hh * ww, hh, ww, "r");
+    x = resnet("mid_block.resnets.1.", x, cm, nullptr, 0, hh * ww, hh, ww, "r", true);
     // ---- 5. up (ref :789-814)
     int cx = cm;
     for (int i = 0; i < n && !R.rc; ++i) {
@@ -605,7 +635,8 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             const Skip sk = skips.back();
             skips.pop_back();
             if (sk.hh != hh || sk.ww != ww) { u->err = "skip size mismatch"; return -1; }
-            x = resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", x, cx, sk.p, sk.ch, hh * ww, hh, ww, (j + i) % 2 ? "r" : "rb");
+            x = resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", x, cx, sk.p, sk.ch, hh * ww, hh, ww, (j + i) % 2 ? "r" : "rb",
+                       has_cross(c, n - 1 - i) || j < Lb || i == n - 1);
             cx = co;
             if (has_cross(c, n - 1 - i))
                 x = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, co, c.heads[n - 1 - i], hh * ww, j % 2 ? "u" : "ub");
@@ -614,6 +645,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             const int ho = skips.back().hh, wo = skips.back().ww;   // = (2 hh, 2 ww) unless a down conv rounded an odd size up
             Run::G g;
             g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = ho; g.Wo = wo; g.upsample = 1;
+            g.defer = 1;   // -> the next block's norm1
             R.gemm(x, 0, B * ho * wo, R.pw("up_blocks." + std::to_string(i) + ".upsamplers.0.conv"), R.buf("us"), g);
             x = R.buf("us");
             hh = ho; ww = wo;

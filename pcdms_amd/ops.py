@@ -24,6 +24,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 BF16 = torch.bfloat16
 LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
 AUTOTUNE = True                    # pick the GEMM tile configuration per problem shape at first use (GPU only)
+DEFER_SPLITK = os.environ.get("PCDM_DEFER_SPLITK", "1") != "0"   # split-K reduce folded into the consuming GroupNorm (A/B switch)
 
 
 def _stream(t: torch.Tensor) -> Optional[int]:
@@ -62,20 +63,59 @@ def groupnorm_cluster_timeouts(ws: torch.Tensor) -> int:
     return int(n.value)
 
 
-def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
+class DeferredGemm:
+    """What ``gemm(..., defer_reduce=True)`` returns when the tuned configuration splits K: the fp32 partial slabs are in the split-K
+    workspace, the reduce launch has NOT run, ``out`` (the bf16 tensor the GEMM would have written) is still unwritten.  The next
+    ``groupnorm`` takes this object as its first source (``pcdm_groupnorm_splitk``): it reduces while it loads, and writes ``out`` iff
+    ``store`` (something else -- a residual, a skip -- reads the tensor later).  Nothing else may touch the split-K workspace in between."""
+
+    __slots__ = ("part", "split_k", "M", "N", "Npad", "bias", "rowvec", "ldrv", "rpb", "residual", "ldr", "out", "store", "keep")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def shape(self):
+        return self.out.shape
+
+    def tensor(self) -> torch.Tensor:
+        """The bf16 tensor -- valid once the consuming GroupNorm has run with ``store``."""
+        assert self.store, "this deferred GEMM's tensor is never written (only its GroupNorm reads it)"
+        return self.out
+
+
+def as_tensor(x: Union[torch.Tensor, "DeferredGemm"]) -> torch.Tensor:
+    return x.tensor() if isinstance(x, DeferredGemm) else x
+
+
+def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
               gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
-    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16."""
+    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16.  x1 may be a ``DeferredGemm``."""
     C1 = x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
-    _c(x1, BF16); _c(out, BF16); _c(gamma, torch.float32); _c(beta, torch.float32)
+    _c(out, BF16); _c(gamma, torch.float32); _c(beta, torch.float32)
     assert ws.numel() >= _lib.lib().pcdm_groupnorm_ws_floats(B, C1 + C2)
-    log = LAUNCH_LOG is not None and x1.is_cuda
+    log = LAUNCH_LOG is not None and out.is_cuda
     if log:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _lib.lib().pcdm_groupnorm(_ptr(x1), C1, _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
-                                  int(silu), _ptr(out), _ptr(ws), _stream(x1))
-    _chk(rc, "pcdm_groupnorm")
+    if isinstance(x1, DeferredGemm):
+        d = x1
+        assert d.M == B * HW and d.N == C1 and (d.rowvec is None or d.rpb == HW), "rowvec rows must be the GroupNorm's batch entries"
+        sp = _lib.GnSplitKSrc()
+        sp.part, sp.split_k, sp.M, sp.N, sp.Npad = d.part, d.split_k, d.M, d.N, d.Npad
+        sp.bias, sp.rowvec, sp.ldrv, sp.residual, sp.ldr = d.bias, d.rowvec, d.ldrv, d.residual, d.ldr
+        sp.pre_out, sp.store_pre = _ptr(_c(d.out, BF16)), int(d.store)
+        rc = _lib.lib().pcdm_groupnorm_splitk(C.byref(sp), _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta), int(silu),
+                                             _ptr(out), _ptr(ws), _stream(out))
+        _chk(rc, "pcdm_groupnorm_splitk")
+        x1 = d.out
+    else:
+        _c(x1, BF16)
+        rc = _lib.lib().pcdm_groupnorm(_ptr(x1), C1, _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
+                                      int(silu), _ptr(out), _ptr(ws), _stream(x1))
+        _chk(rc, "pcdm_groupnorm")
     if log:   # algorithmic bytes: the tensor read once + written once (SURVEY.md §8d)
         e1.record()
         LAUNCH_LOG.append(("groupnorm", 2.0 * B * HW * (C1 + C2) * 2, e0, e1, (B, HW, C1 + C2)))
@@ -191,14 +231,20 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
-         ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None) -> torch.Tensor:
+         ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
+         defer_reduce: Optional[bool] = None) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
     ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  With ``pw_ln`` (the same Linear packed by ``pack_linear_ln`` /
     ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..34, K = 320; 34 = four waves, two workgroups per CU: the one in use) needs no LayerNorm pass
     at all -- it takes the row statistics from the rows it holds; for every other tile the rows go through ``pcdm_layernorm`` into
-    ``ln_buf`` [M, K] first (the tuner times both forms, the LayerNorm launch included, and keeps the faster)."""
+    ``ln_buf`` [M, K] first (the tuner times both forms, the LayerNorm launch included, and keeps the faster).
+
+    ``defer_reduce`` (``True``: the reduced tensor is also read by something other than the next GroupNorm -- it gets written by that
+    GroupNorm; ``False``-but-not-``None`` i.e. ``0``: only the next GroupNorm reads it): when the configuration in use splits K, skip the
+    reduce launch and return a ``DeferredGemm`` for ``ops.groupnorm`` to consume.  The caller promises that the very next user of the
+    result is that GroupNorm and that no other split-K GEMM runs in between.  ``None``: never defer."""
     if ln is not None and conv is None and a2 is None and ln_buf is not None:
         return _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0,
                         tile=tile)
@@ -249,18 +295,25 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.ldo2 = out2.shape[-1]
     stream = _stream(a)
     split = 1
-    if tile == 0 and AUTOTUNE and a.is_cuda:
+    if tile == 0 and AUTOTUNE:
         key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
                a2 is not None, residual is not None) + ((True,) if zero_rows else ())   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
-        if tile == 0 and not torch.cuda.is_current_stream_capturing():
+        if tile == 0 and a.is_cuda and not torch.cuda.is_current_stream_capturing():   # (the emulator build runs the library's heuristic)
             tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device, out)
     elif split_k > 1:
         split = split_k
     p.tile = tile
+    deferred = None
     if split > 1:
         ws = _splitk_ws(a.device, split * M * pw.Npad)
         p.split_k, p.ws, p.ws_floats = split, ws.data_ptr(), ws.numel()
+        if defer_reduce is not None and DEFER_SPLITK and epilogue == EPI_STORE and act == ACT_NONE and (residual is None or res_mod in (0, M)) \
+                and (rowvec is None or (rows_per_batch and M % rows_per_batch == 0)) and out.is_contiguous() and out.shape == (M, pw.N):
+            p.defer_reduce = 1
+            deferred = DeferredGemm(part=ws.data_ptr(), split_k=split, M=M, N=pw.N, Npad=pw.Npad, bias=p.bias, rowvec=p.rowvec,
+                                    ldrv=p.ldrv if rowvec is not None else 0, rpb=p.rows_per_batch, residual=p.residual, ldr=p.ldr, out=out,
+                                    store=bool(defer_reduce), keep=(ws, rowvec, residual, pw))
     if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -270,9 +323,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         # field is what the launch executes
         LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split),
                            2.0 * (M - zero_rows) * pw.alg_nk))
-        return out
+        return out if deferred is None else deferred
     _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
-    return out
+    return out if deferred is None else deferred
 
 
 def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile):

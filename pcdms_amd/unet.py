@@ -557,26 +557,34 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         temb = ops.gemm(emb_bf, W["temb"], self._buf("temb", (B, W["temb_n"]), torch.float32), rows_per_batch=1,
                         epilogue=ops.EPI_NCHW_F32)                      # fp32 [B, 20160] (rows_per_batch = 1: "NCHW" == row-major)
 
-        def resnet(p, x1, x2, HW_, hh, ww, name):
+        # Split-K convolutions (levels 1-3: M <= 11264 rows against K up to 23040) leave their fp32 partial slabs for the GroupNorm that
+        # always follows -- conv1 -> norm2, conv2 / down- / upsampling conv -> the next block's first norm -- which reduces them while it
+        # loads its slab (ops.DeferredGemm / pcdm_groupnorm_splitk): no reduce launch, no bf16 round trip in front of the norm.  The bf16
+        # tensor itself is written by that norm where a residual, shortcut or skip connection reads it later (`gn_next`: the caller
+        # knows whether the next consumer of the block's output is a GroupNorm).
+        def resnet(p, x1, x2, HW_, hh, ww, name, gn_next=False):
             r = W[p]
             cin, cout, M = r["cin"], r["cout"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
+            x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
             cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
             tv = temb[:, r["toff"]: r["toff"] + cout]
-            h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_)
+            h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False)
             n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
             else:
                 res = x1
-            return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M)
+            return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M,
+                            defer_reduce=True if gn_next else None)
 
         def transformer(p, x, HW_, name):
             a = W[p]
             c, H, M = a["c"], a["heads"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
+            x = ops.as_tensor(x)
             t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)))
             # self-attention
             # LayerNorm -> projection pairs go through ops.gemm(ln=...): at K = 320 (level 0) the A-in-registers kernel takes the weights
@@ -618,40 +626,46 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         skips: List[Tuple[torch.Tensor, int, int]] = [(x, h, w)]
         hh, ww = h, w
         L_ = self._layers[0]
+
+        def skip_of(t):   # (a deferred tensor's buffer: filled by the norm that follows, long before the up path reads it)
+            return t.out if isinstance(t, ops.DeferredGemm) else t
         for i, typ in enumerate(cfg.down_block_types):
             for j in range(L_):
                 nm = f"d{i}.{j}"
                 if typ == "CrossAttnDownBlock2D":
-                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r")
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r", gn_next=True)
                     x = transformer(f"down_blocks.{i}.attentions.{j}.", x, hh * ww, nm)
-                else:
-                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm)
-                skips.append((x, hh, ww))
+                else:   # the next consumer is a resnet's norm1 (same block, or the mid block) unless a downsampling conv follows
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm, gn_next=j < L_ - 1 or i == nlev - 1)
+                skips.append((skip_of(x), hh, ww))
             if i != nlev - 1:
                 ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
                 x = ops.gemm(x.view(B, hh, ww, boc[i]), W[f"down_blocks.{i}.downsamplers.0.conv."],
                              self._buf(f"ds{i}", (B * ho * wo, boc[i])),
-                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, stride=2))
+                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, stride=2), defer_reduce=True)   # -> the next block's norm1
                 hh, ww = ho, wo
-                skips.append((x, hh, ww))
+                skips.append((skip_of(x), hh, ww))
         # ---- 4. mid (ref :775-783)
-        x = resnet("mid_block.resnets.0.", x, None, hh * ww, hh, ww, "r")
+        x = resnet("mid_block.resnets.0.", x, None, hh * ww, hh, ww, "r", gn_next=True)
         x = transformer("mid_block.attentions.0.", x, hh * ww, "r2")
-        x = resnet("mid_block.resnets.1.", x, None, hh * ww, hh, ww, "r")
+        x = resnet("mid_block.resnets.1.", x, None, hh * ww, hh, ww, "r", gn_next=True)
         # ---- 5. up (ref :789-814)
         rev = list(reversed(boc))
         for i, typ in enumerate(cfg.up_block_types):
             for j in range(L_ + 1):
                 sk, sh, sw = skips.pop()
                 assert (sh, sw) == (hh, ww)
-                x = resnet(f"up_blocks.{i}.resnets.{j}.", x, sk, hh * ww, hh, ww, "r" if (j + i) % 2 else "rb")
-                if typ == "CrossAttnUpBlock2D":
+                cross = typ == "CrossAttnUpBlock2D"
+                # next consumer: the transformer's norm, the next resnet's norm1, conv_norm_out -- or the upsampling conv (no norm)
+                x = resnet(f"up_blocks.{i}.resnets.{j}.", x, sk, hh * ww, hh, ww, "r" if (j + i) % 2 else "rb",
+                           gn_next=cross or j < L_ or i == nlev - 1)
+                if cross:
                     x = transformer(f"up_blocks.{i}.attentions.{j}.", x, hh * ww, "u" if j % 2 else "ub")
             if i != nlev - 1:
                 ho, wo = skips[-1][1], skips[-1][2]      # = (2 hh, 2 ww) unless a down conv rounded an odd size up
                 x = ops.gemm(x.view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
                              self._buf("us", (B * ho * wo, rev[i])),
-                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, upsample=1))
+                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, upsample=1), defer_reduce=True)    # -> the next block's norm1
                 hh, ww = ho, wo
         # ---- 6. post-process (ref :817-820)
         ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)

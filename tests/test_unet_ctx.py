@@ -133,3 +133,41 @@ def test_pipeline_with_c_schedule_equals_python_schedule(backend):
         assert torch.equal(a, b), (sched.__name__, (a - b).abs().max())
         if not backend.is_emu:
             assert torch.equal(pc(**kw).latents, b)      # replay
+
+
+def test_splitk_deferral_through_both_schedules(backend, monkeypatch):
+    """The split-K reduce folded into the consuming GroupNorm (``ops.DeferredGemm`` / the C schedule's pending reduce), at the level of a
+    whole forward: every convolution of the tiny UNet is forced onto a split-K configuration, then the forward with the fold must equal
+    the forward without it (``PCDM_DEFER_SPLITK=0``) BIT FOR BIT, in the Python schedule and in ``pcdm_unet_forward``."""
+    cfg = UNetConfig.tiny()
+    B, h, w, L, n0 = (2, 8, 8, 5, 1) if backend.is_emu else (4, 16, 24, 9, 2)
+
+    class Rec(dict):
+        seen: list = []
+
+        def get(self, k, d=None):
+            self.seen.append(k)
+            return super().get(k, d)
+
+    rec = Rec(ops._TUNED)
+    monkeypatch.setattr(ops, "_TUNED", rec)
+    _run_both(backend, cfg, B, h, w, L, n0)           # records the problem keys of one forward (and tunes them on the GPU)
+    forced = 0
+    for k in set(rec.seen):
+        if isinstance(k[0], int) and k[3] and k[6] == ops.EPI_STORE and k[2] // 64 >= 4 and k[1] % 64 == 0:   # conv3x3, plain store
+            dict.__setitem__(rec, k, (2, 2))          # 64x64 tiles, K split in two
+            forced += 1
+    assert forced >= 6
+    monkeypatch.setattr(ops, "DEFER_SPLITK", False)
+    monkeypatch.setenv("PCDM_DEFER_SPLITK", "0")
+    _, _, ref_py, ref_c = _run_both(backend, cfg, B, h, w, L, n0)
+    monkeypatch.setattr(ops, "DEFER_SPLITK", True)
+    monkeypatch.setenv("PCDM_DEFER_SPLITK", "1")
+    made = []
+    orig = ops.DeferredGemm.__init__
+    monkeypatch.setattr(ops.DeferredGemm, "__init__", lambda self, **kw: (made.append(kw["store"]), orig(self, **kw))[1])
+    _, _, out_py, out_c = _run_both(backend, cfg, B, h, w, L, n0)
+    assert len(made) >= 2 * forced - 4 and any(made) and not all(made)   # conv1s (not stored) and conv2s / resampling convs (stored)
+    assert torch.equal(ref_py, ref_c)
+    assert torch.equal(out_py, ref_py), (out_py - ref_py).abs().max()
+    assert torch.equal(out_c, ref_py), (out_c - ref_py).abs().max()
