@@ -40,6 +40,12 @@ def _stale(out: Path, deps) -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     LIBDIR.mkdir(exist_ok=True)
+    # the -D defines of the last build are part of the staleness check: an A/B build (PCDM_BUILD_DEFINES=...) must never silently
+    # reuse objects compiled without them, nor the default build objects compiled with them
+    defines = " ".join(sorted(os.environ.get("PCDM_BUILD_DEFINES", "").split()))
+    stamp = LIBDIR / "build_defines.txt"
+    if not stamp.exists() or stamp.read_text() != defines:
+        force = True
     headers = [CSRC / "pcdm_device.h", CSRC / "gemm_args.h", ROOT.parent / "include" / "pcdm.h"]
     objs, jobs = [], []
     for src in SOURCES:
@@ -62,6 +68,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    stamp.write_text(defines)
     return LIB
 
 

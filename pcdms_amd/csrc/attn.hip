@@ -251,16 +251,41 @@ __global__ __launch_bounds__(256, 3) void flash_attn_fp8_kernel(const u16* __res
     const bool qvalid = qrow < Lq;
     if (!qvalid) qrow = Lq - 1;
     const u16* qp = q + ((int64_t)b * Lq + qrow) * ldq + h * 64 + hh * 32;
+    // Range guard (VERDICT r3 #3e): e4m3 tops out at 448.  A query whose scaled row q c exceeds that (large to_q gains of a trained
+    // checkpoint, outlier channels) is multiplied by a power of two 2^-e that brings its largest element back into range -- exact, its
+    // scores are multiplied back by 2^e in fp32 behind the QK^T MFMA -- instead of being clamped (which silently changed the scores).
+    // Rows in range (every row of the UNet's LayerNorm-fed to_q with unit-gain weights) take the old path: one wave-uniform branch per tile.
     u32x8 qf;
+    float q_up = 1.0f;                 // 2^e of this lane's query
+    {
+        u16x8 raw[4];
+        float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u16x8 raw = *(const u16x8*)(qp + i * 8);
-        float f[8];
+        for (int i = 0; i < 4; ++i) {
+            raw[i] = *(const u16x8*)(qp + i * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(raw[e]) * c, -448.f), 448.f);
-        qf[2 * i] = pack4_fp8(f[0], f[1], f[2], f[3]);
-        qf[2 * i + 1] = pack4_fp8(f[4], f[5], f[6], f[7]);
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(raw[i][e]) * c));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));          // the other 32 dims of the same query
+        float q_dn = 1.0f;
+        if (amax > 448.f && amax < 3.0e38f) {
+            // smallest e with amax 2^-e <= 448: from the exponent field of amax / 448 (rounded up)
+            const uint32_t bits = __builtin_bit_cast(uint32_t, amax * (1.0f / 448.f));
+            const int ex = (int)((bits >> 23) & 255) - 127 + ((bits & 0x7fffffu) ? 1 : 0);
+            q_dn = __builtin_bit_cast(float, (uint32_t)((127 - ex) << 23));
+            q_up = __builtin_bit_cast(float, (uint32_t)((127 + ex) << 23));
+        }
+        const float cq = c * q_dn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(raw[i][e]) * cq, -448.f), 448.f);   // (only NaN / inf rows still clamp)
+            qf[2 * i] = pack4_fp8(f[0], f[1], f[2], f[3]);
+            qf[2 * i + 1] = pack4_fp8(f[4], f[5], f[6], f[7]);
+        }
     }
+    const bool q_rescaled = wave_any(q_up != 1.0f);   // wave-uniform
 
     // LDS-DMA staging: one K and one V^T instruction per wave per tile (1 KiB = 16 rows of 64 B each)
     constexpr uint32_t kOOB = 0x80000000u;
@@ -307,6 +332,12 @@ __global__ __launch_bounds__(256, 3) void flash_attn_fp8_kernel(const u16* __res
         for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_f8_32x32x64(kfr[kf], qf, s[kf]);
+        if (q_rescaled) {   // (rare: see the range guard above)
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kf][r] *= q_up;
+        }
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(ones, qm, s[kf]);   // S' = S - m_ref
         // V^T operands of this tile (their LDS latency hides behind the softmax): row d = 32 df + col, k-slots [16hh.. | 32+16hh..]

@@ -169,6 +169,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PCDM_GELU_Q3 (-0.051827382296323776f)
 #define PCDM_GELU_Q4 (0.007084557320922613f)
 #define PCDM_GELU_Q5 (-0.0004733092791866511f)
+#ifdef PCDM_GELU_AS7126   // (A/B build, tools/README.md: the Abramowitz-Stegun form of rounds 1-3)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * fast_exp2(-1.44269504088896341f * z * z);   // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
+}
+__device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) { return f32x2{gelu_erf_f(x[0]), gelu_erf_f(x[1])}; }
+#else
 __device__ __forceinline__ float gelu_erf_f(float x) {
     const float t = fminf(fabsf(x), 6.0f);
     const float q = PCDM_GELU_Q0 + t * (PCDM_GELU_Q1 + t * (PCDM_GELU_Q2 + t * (PCDM_GELU_Q3 + t * (PCDM_GELU_Q4 + t * PCDM_GELU_Q5))));
@@ -185,6 +195,7 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
     const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
     return r - t * e;
 }
+#endif
 // v[e] = h[e] * gelu(g[e]), e = 0..3 (one accumulator quad of the GEGLU epilogues)
 __device__ __forceinline__ f32x4 geglu_quad(f32x4 h, f32x4 g) {
     const f32x2 a = gelu_erf_f2(f32x2{g[0], g[1]}), b = gelu_erf_f2(f32x2{g[2], g[3]});

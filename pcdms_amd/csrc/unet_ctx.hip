@@ -47,7 +47,10 @@ struct pcdm_unet {
     std::tuple<int, int, int, int> plan_key{0, 0, 0, 0};
     std::map<std::string, Buf> bufs;
     int64_t ws_bytes = 0;
-    int n0 = 0;   // leading batch entries with an all-zero context (set by prepare_conditioning)
+    // per WORKSPACE: what the last prepare_conditioning on it was given -- the shape, n0 = leading batch entries with an all-zero context, pose_b.
+    // forward() takes n0 from the workspace it runs on (a host may alternate workspaces / batch shapes on one context) and refuses a
+    // workspace whose conditioning was never prepared or was prepared for another batch / pose layout
+    std::map<const void*, std::tuple<int, int, int, int, int, int>> cond_of_ws;   // {B, h, w, L, n0, pose_b}
     std::string err;
 };
 
@@ -385,6 +388,7 @@ extern "C" int pcdm_unet_set_weight(pcdm_unet* u, const char* name, const void* 
     p.w = w; p.bias = bias; p.wsum = wsum; p.N = N; p.K = K; p.Npad = Npad; p.cin = cin;
     u->w[name] = p;
     u->bufs.clear();
+    u->cond_of_ws.clear();   // (the plan is rebuilt: buffers move)
     return 0;
 }
 
@@ -432,7 +436,7 @@ extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w,
     int n0 = zero_ctx_batches;
     if (n0 < 0 || n0 > B) return -1;
     if (n0 == B) n0 = B > 1 ? B - 1 : 0;
-    u->n0 = n0;
+    u->cond_of_ws[workspace] = std::make_tuple(B, h, w, L, n0, pose ? pose_b : 0);
     if (c.class_embed) {
         if (!class_labels) return -1;
         const PW *c1 = R.pw("class_embedding.linear_1"), *c2 = R.pw("class_embedding.linear_2");
@@ -480,7 +484,14 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     const float eps = c.norm_eps;
     int temb_n = 0;
     const std::map<std::string, int> toff = temb_offsets(c, &temb_n);
-    const int n0 = u->n0;
+    const auto cit = u->cond_of_ws.find(workspace);
+    if (cit == u->cond_of_ws.end() || std::make_tuple(B, h, w, L) != std::make_tuple(std::get<0>(cit->second), std::get<1>(cit->second), std::get<2>(cit->second),
+                                                                                      std::get<3>(cit->second)) || std::get<5>(cit->second) != pose_b) {
+        u->err = cit == u->cond_of_ws.end() ? "pcdm_unet_prepare_conditioning has not run on this workspace"
+                                            : "this workspace's conditioning was prepared for another shape / pose_b";
+        return -1;
+    }
+    const int n0 = std::get<4>(cit->second);
 
     // ---- 1. time / class embedding (ref :661-708)
     R.chk(pcdm_timestep_embedding(t_dev, step_dev, R.buf<float>("t_emb"), B, C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding");

@@ -349,13 +349,19 @@ class Stage2_InpaintDiffusionPipeline:
             if self._ctx is None or self._ctx._pack_gen != unet._pack_gen or self._ctx.unet is not unet:
                 self._ctx = UNetContext(unet)
                 self._graph = None
-            if self._graph is None and dev.type == "cuda":   # one Python-schedule step first: it tunes every GEMM shape of this batch size
+            # one Python-schedule step first, once per (context, weights, workspace): it tunes every GEMM shape of this batch size.  The
+            # device step counter is reset BEFORE it (a reused `st` still holds the last run's count, one past the end of the
+            # timestep / coefficient tables: ADVICE r3)
+            if st.get("c_tuned") != (id(self._ctx), w_gen) and dev.type == "cuda":
                 lat0 = lat.clone()
+                st["step"].zero_()
+                self._zero_history(st)
                 self._step_eager(st)
                 st["lat"].copy_(lat0)
                 st["step"].zero_()
                 self._zero_history(st)
                 self._ctx.sync_tiles()
+                st["c_tuned"] = (id(self._ctx), w_gen)
             st["pose_b"] = self._ctx.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
             st["eps_c"] = st.get("eps_c") if st.get("eps_c") is not None and st["eps_c"].shape[0] == B else \
                 torch.empty(B, unet.config.out_channels, h, w, dtype=torch.float32, device=dev)

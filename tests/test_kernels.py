@@ -489,6 +489,49 @@ def test_flash_attn_fp8(backend, case):
     assert torch.isfinite(o).all() and r1 <= 4e-2 and r2 <= 8e-2, (r1, r2)
 
 
+def test_flash_attn_fp8_hot_queries(backend):
+    """Range guard of the fp8 attention (VERDICT r3 #3e): queries whose scaled rows ``q * scale * log2e`` exceed e4m3's 448 (to_q gains of a
+    trained checkpoint, outlier channels) used to be CLAMPED, silently changing their scores.  They are now divided by a per-query power
+    of two before the conversion and their scores multiplied back in fp32 -- exact.  Every third query carries one huge component
+    (+-6000, ~2.4x the clamp point) against a key column of +-2^-9 (exact in e4m3), i.e. +-1.46 of its scores ride on that component (+-0.61 when clamped); a
+    second outlier group sits just BELOW the limit (no rescale).  Checked against fp32 attention on the same quantised operands."""
+    dev = backend.device
+    B, H, Lq, Lk = (1, 1, 48, 70) if backend.is_emu else (2, 5, 1408, 1408)
+    Cc = H * 64
+    q, k, v = rnd(B * Lq, Cc, seed=170).float(), rnd(B * Lk, Cc, seed=171).float(), rnd(B * Lk, Cc, seed=172)
+    sgn = (torch.rand(B * Lk, generator=torch.Generator().manual_seed(173)) < 0.5).float() * 2 - 1
+    for hd in range(H):
+        k[:, hd * 64 + 7] = sgn * 2.0 ** -9
+        k[:, hd * 64 + 9] = -sgn * 2.0 ** -9
+        q[0::3, hd * 64 + 7] = 6000.0      # rescaled rows (6000 * 0.18 = 1082 > 448)
+        q[1::3, hd * 64 + 9] = -2400.0     # just inside (2400 * 0.18 = 433): must stay on the plain path
+    q, k = q.to(BF16), k.to(BF16)
+    Lp = (Lk + 15) // 16 * 16
+    k8 = torch.empty(B * Lk, Cc, dtype=torch.uint8, device=dev)
+    ops.quantize_fp8(k.to(dev), k8)
+    vt = v.view(B, Lk, Cc).permute(0, 2, 1).contiguous().view(B * Cc, Lk)
+    vt8 = torch.zeros(B * Cc, Lp, dtype=torch.uint8, device=dev)
+    ops.quantize_fp8(vt.to(dev), vt8, cols=Lk)
+    out = torch.empty(B * Lq, Cc, dtype=BF16, device=dev)
+    ops.flash_attn_fp8(q.to(dev), k8, vt8.view(B, Cc, Lp), out, B, H, Lq, Lk)
+    backend.sync()
+    # reference on the quantised operands: a row's own power of two commutes with the e4m3 rounding (barring underflow of its small elements)
+    c = 0.125 * 1.44269504088896341
+    qs = q.float() * c
+    amax = qs.view(B * Lq, H, 64).abs().amax(-1, keepdim=True)
+    e = torch.where(amax > 448, torch.ceil(torch.log2(amax / 448)), torch.zeros_like(amax))
+    qq = (_e4m3((qs.view(B * Lq, H, 64) * 2.0 ** -e)) * 2.0 ** e).view(B * Lq, Cc) / c
+    ref_q = _attn_ref(qq, _e4m3(k), _e4m3(v), B, H, Lq, Lk)
+    o = out.float().cpu()
+    for rows in (slice(0, None, 3), slice(1, None, 3), slice(2, None, 3)):
+        r = ((o[rows] - ref_q[rows]).norm() / ref_q[rows].norm()).item()
+        assert torch.isfinite(o).all() and r <= 4e-2, (rows, r)
+    # what clamping would have given is measurably different -- the test would have caught the old behaviour
+    qc = (_e4m3((q.float() * c).clamp(-448, 448)) / c)
+    ref_clamped = _attn_ref(qc, _e4m3(k), _e4m3(v), B, H, Lq, Lk)
+    assert ((ref_clamped[0::3] - ref_q[0::3]).norm() / ref_q[0::3].norm()).item() > 0.2
+
+
 # ------------------------------------------------------------------------------------------------ small ops
 def test_timestep_embedding_and_small_linear(backend):
     dev = backend.device

@@ -58,8 +58,46 @@ def test_c_schedule_full_size_and_graph_capture(gpu_backend):
     """The 868.9 M-parameter configuration at latent 64x88, UNet batch 8 (BASELINE.json configs[1]): C schedule == Python schedule, also
     when the single C call is captured into a hipGraph and replayed with the timestep taken from a device table."""
     cfg = UNetConfig()
-    sd, (s, e, c, p), ref, out = _run_both(gpu_backend, cfg, 8, 64, 88, 258, 4)
-    assert torch.equal(out, ref), (out - ref).abs().max()
+    dev = gpu_backend.device
+    B, h, w, L, n0 = 8, 64, 88, 258, 4
+    sd = synth_state_dict(cfg, seed=3, random_affine=True)
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(dev)
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(B, cfg.in_channels, h, w, generator=g)
+    e = torch.randn(B, L, cfg.cross_attention_dim, generator=g)
+    e[:n0] = 0
+    c = torch.randn(B, 1, cfg.projection_class_embeddings_input_dim, generator=g) * 0.4
+    p = torch.randn(1, cfg.block_out_channels[0], h, w, generator=g) * 0.1
+    # a device timestep TABLE and a device step counter: what the sampler's captured step reads (nothing host-side changes between replays)
+    ts = torch.tensor([417, 801, 33], dtype=torch.int64, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    cond = m.prepare_conditioning(B, h, w, e.to(dev), c.to(dev), p.to(dev), zero_ctx_batches=n0)
+    x_in = ops.nchw_to_nhwc_bf16(s.to(dev), cpad=m._w["conv_in"].cin)
+    refs = []
+    for i in range(3):       # Python schedule, eager, at the three timesteps (the first pass tunes unseen shapes)
+        step.fill_(i)
+        refs.append(m._forward_nhwc(x_in, B, h, w, ts, cond, step).clone())
+    assert not torch.equal(refs[0], refs[1])
+    ctx = UNetContext(m)
+    pose_b = ctx.prepare_conditioning(B, h, w, e, c, p, zero_ctx_batches=n0)
+    out = torch.empty_like(refs[0])
+    step.fill_(0)
+    ctx.forward(x_in, ts, step, B, h, w, pose_b, out=out)            # eager C schedule
+    torch.cuda.synchronize()
+    assert torch.equal(out, refs[0]), (out - refs[0]).abs().max()
+    # ---- the single C call captured into a hipGraph, replayed with the step counter advanced on the device
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        ctx.forward(x_in, ts, step, B, h, w, pose_b, out=out)
+    for i in (1, 2, 0, 1):
+        step.fill_(i)
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, refs[i]), (i, (out - refs[i]).abs().max())
 
 
 @pytest.mark.gpu
