@@ -128,8 +128,14 @@ typedef struct pcdm_gemm_params {
                               pcdm_groupnorm_splitk (the GroupNorm that follows every split-K convolution of the UNet: conv1 -> norm2, conv2 ->
                               the next block's norm) reads the slabs, so the reduce launch, its bf16 write and the norm's read of it disappear.
                               ws must stay untouched until that consumer has run (same stream). */
+    int32_t dup_rows;      /* conv3x3 + PCDM_EPI_STORE only, > 0: the M rows computed are ALSO written as rows m + dup_rows of out (which then has
+                              M + dup_rows rows), with the row-vector row (m + dup_rows) / rows_per_batch and the residual row m + dup_rows of
+                              their own: one contraction, two epilogues.  For a batch whose second half has the same conv INPUT as the first
+                              but its own time embedding -- the two classifier-free-guidance halves at conv_in and at the first ResnetBlock2D's
+                              conv1 (stage2_inpaint_pipeline.py:499-501 doubles the latents; mask, masked latents and pose are shared).  Needs
+                              N % 8 == 0, ldo % 8 == 0, rows_per_batch >= 32 and dup_rows % rows_per_batch == 0 with a rowvec; else -1 */
 } pcdm_gemm_params;
-/* pcdm_version() == 2: the struct above ends with defer_reduce (1: ended with ln_eps).  Zero-initialise it (memset) and build against
+/* pcdm_version() == 2: the struct above ends with defer_reduce, dup_rows (1: ended with ln_eps).  Zero-initialise it (memset) and build against
  * the header of the library in use: a host compiled against an older header passes a shorter struct. */
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 
@@ -266,6 +272,10 @@ int pcdm_unet_workspace_init(pcdm_unet* u, int B, int h, int w, int L, void* wor
  * NULL; zero_ctx_batches: leading batch entries of ehs that are all-zero (the CFG unconditional half: their cross-attention is skipped) */
 int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w, int L, const float* ehs, const float* class_labels, const float* pose, int pose_b,
                                    int zero_ctx_batches, void* workspace, pcdm_stream_t s);
+/* Optional, after pcdm_unet_prepare_conditioning on the same workspace: the caller guarantees that batch entries b and b + B/2 always carry the
+ * same x_in rows and pose feature (the two classifier-free-guidance halves: stage2_inpaint_pipeline.py:499-501 doubles the latents and shares
+ * mask / masked latents / pose): conv_in, the first norm1 and the first conv1's contraction then run once for both halves. */
+int pcdm_unet_set_shared_cfg_input(pcdm_unet* u, void* workspace, int shared);
 /* x_in NHWC bf16 [B, h, w, conv_in.cin] (pcdm_assemble_input / pcdm_nchw_f32_to_nhwc_bf16); timestep = t_dev[step_dev ? *step_dev : 0] (device);
  * pose_b as passed to prepare_conditioning (0: no pose); eps_out fp32 NCHW [B, out_channels, h, w] */
 int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* t_dev, const int32_t* step_dev, int B, int h, int w, int L, int pose_b,

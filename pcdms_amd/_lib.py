@@ -40,7 +40,7 @@ class GemmParams(C.Structure):
         ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32), ("act", C.c_int32),
         ("zero_rows", C.c_int32),
-        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
+        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32), ("dup_rows", C.c_int32),
     ]
 
 
@@ -100,6 +100,7 @@ _SIGS = {
     "pcdm_unet_workspace_bytes": ([_P, _I, _I, _I, _I], _L),
     "pcdm_unet_workspace_init": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "pcdm_unet_prepare_conditioning": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P], C.c_int),
+    "pcdm_unet_set_shared_cfg_input": ([_P, _P, _I], C.c_int),
     "pcdm_unet_forward": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "pcdm_pack_linear": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),
     "pcdm_pack_conv3x3": ([_P, _P, _I, _I, _I, _P, _P, _P, _P], C.c_int),

@@ -623,10 +623,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         constexpr int EPW = CG * F + 4;                    // fp32 row pitch (conflict-free ds_write_b128)
         const bool has_res = p.residual != nullptr && !geglu, has_rv = p.rowvec != nullptr && !geglu;
         const int ncols_out = qk_tile ? p.vt_col0 : p.N;   // extent of a row of `out`
-        const BufRsrc rs_o = make_buf_rsrc(p.out, (uint32_t)((((int64_t)p.M - 1) * p.ldo + ncols_out) * 2));
-        const BufRsrc rs_r = make_buf_rsrc(has_res ? (const void*)p.residual : (const void*)p.out,
+        // dup_rows (conv only): the whole epilogue runs a second time on the same accumulators for the output rows m + dup_rows -- with the
+        // row-vector rows, residual rows and output rows of THAT half: the descriptors of repetition 1 are based dup_rows rows further,
+        // every offset below stays relative to m (rows >= M are still dropped by the bounds check).  The CFG-shared prefix of the UNet:
+        // both halves of the batch have the same input, so conv_in and the first resnet's conv1 are contracted once and written twice.
+        auto epilogue_rep = [&](auto rep_tag) {
+        constexpr int REP = decltype(rep_tag)::value;      // 0: rows m; 1 (conv, dup_rows > 0 only): rows m + dup_rows
+        const int64_t sh = REP ? (int64_t)p.dup_rows : 0;
+        const BufRsrc rs_o = make_buf_rsrc((const char*)p.out + sh * p.ldo * 2, (uint32_t)((((int64_t)p.M - 1) * p.ldo + ncols_out) * 2));
+        const BufRsrc rs_r = make_buf_rsrc(has_res ? (const void*)(p.residual + sh * p.ldr) : (const void*)p.out,
                                            has_res ? (uint32_t)((((int64_t)p.M - 1) * p.ldr + p.N) * 2) : 0u);
-        const BufRsrc rs_v = make_buf_rsrc(has_rv ? (const void*)p.rowvec : (const void*)p.out,
+        const float* rowvec_rep = (has_rv && REP) ? p.rowvec + (sh / p.rows_per_batch) * p.ldrv : p.rowvec;
+        const BufRsrc rs_v = make_buf_rsrc(has_rv ? (const void*)rowvec_rep : (const void*)p.out,
                                            has_rv ? (uint32_t)((((int64_t)(p.M - 1) / p.rows_per_batch) * p.ldrv + p.N) * 4) : 0u);
         const BufRsrc rs_vt = make_buf_rsrc(v_tile ? (const void*)p.out2 : (const void*)p.out,
                                             v_tile ? (uint32_t)((int64_t)(p.M / p.rows_per_batch) * (p.N - p.vt_col0) * p.ldo2 * 2) : 0u);
@@ -644,24 +652,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         const int rv_blo = wrow0 / p.rows_per_batch;
         const bool rv_lds = has_rv && (wrow0 + WM - 1) / p.rows_per_batch <= rv_blo + 1;
         const int rv_split_row = (rv_blo + 1) * p.rows_per_batch;
-        if (lane * 4 < WN) {
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            *(f32x4*)(bias_w + lane * 4) = p.bias ? *(const f32x4*)(p.bias + wcol0 + lane * 4) : z4;
-            if (rv_lds) {
-                const int c = wcol0 + lane * 4;
-                const int nb = (p.M - 1) / p.rows_per_batch;
+        {
+            if (REP) PCDM_WAVE_SYNC();   // (the first repetition's reads of the wave's LDS slices are done)
+            if (lane * 4 < WN) {
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                if (!REP) *(f32x4*)(bias_w + lane * 4) = p.bias ? *(const f32x4*)(p.bias + wcol0 + lane * 4) : z4;
+                if (rv_lds) {
+                    const int c = wcol0 + lane * 4;
+                    const int nb = (p.M - 1) / p.rows_per_batch;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int b = rv_blo + h < nb ? rv_blo + h : nb;
-                    f32x4 v = z4;
+                    for (int h = 0; h < 2; ++h) {
+                        const int b = rv_blo + h < nb ? rv_blo + h : nb;
+                        f32x4 v = z4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < p.N) v[e] = p.rowvec[(int64_t)b * p.ldrv + c + e];
-                    *(f32x4*)(rvec_w + h * WNP + lane * 4) = v;
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < p.N) v[e] = rowvec_rep[(int64_t)b * p.ldrv + c + e];
+                        *(f32x4*)(rvec_w + h * WNP + lane * 4) = v;
+                    }
                 }
             }
+            PCDM_WAVE_SYNC();
         }
-        PCDM_WAVE_SYNC();
         constexpr int NCG = (FN + CG - 1) / CG, NJB = WM / 32;
         // pass q = (column group q / NJB, row block q % NJB); GEGLU needs WN == 64, i.e. a single column group
         // The pass loop exists twice: with and without a residual operand.  The residual rows of ALL passes sit in registers from before
@@ -785,6 +796,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         };
         if (has_res) run_passes(std::true_type());
         else run_passes(std::false_type());
+        };   // epilogue_rep
+        epilogue_rep(std::integral_constant<int, 0>());
+        if constexpr (CONV) {   // (the second half of a dup_rows launch: its own output / residual / row-vector rows, the same accumulators)
+            if (p.dup_rows > 0) epilogue_rep(std::integral_constant<int, 1>());
+        }
 #ifndef PCDM_EMU
         if ((p.debug & 4) && p.ws) {
             PCDM_STAMP(4);
@@ -1040,6 +1056,13 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.tiles_m = a.tiles_n = 0;
     a.debug = p->tile >> 8;
     a.act = p->act;
+    a.dup_rows = p->dup_rows;
+    if (a.dup_rows) {   // the lean (LDS-staged) epilogue of a convolution only: everything it needs is known here
+        if (a.dup_rows < 0 || !p->conv || p->epilogue != PCDM_EPI_STORE || p->act || p->split_k > 1 || (p->N & 7) || (p->ldo & 7)) return -1;
+        if (p->residual && ((p->ldr & 7) || (p->res_mod > 0 && p->res_mod < p->M))) return -1;
+        if (p->rowvec && (p->rows_per_batch < 32 || a.dup_rows % p->rows_per_batch)) return -1;
+        if (((int64_t)p->M + a.dup_rows) * (p->ldo > 0 ? p->ldo : p->N) * 2 >= lim) return -2;
+    }
     a.zero_rows = p->zero_rows;
     if (a.zero_rows < 0 || a.zero_rows > p->M || (a.zero_rows && p->conv)) return -1;
     if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act == PCDM_ACT_GELU && p->epilogue == PCDM_EPI_GEGLU)) return -1;

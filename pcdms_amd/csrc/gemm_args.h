@@ -35,6 +35,7 @@ struct GemmArgs {
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
     const float* ln_wsum;    // rowgemm only: the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
     float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
+    int dup_rows;       // conv, lean epilogue: also write rows m + dup_rows (their own rowvec / residual rows): pcdm_gemm_params.dup_rows
     int defer_reduce;   // split_k > 1: no reduce launch (pcdm_groupnorm_splitk consumes the partial slabs)
     int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
                 // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)

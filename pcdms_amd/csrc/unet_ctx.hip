@@ -50,7 +50,7 @@ struct pcdm_unet {
     // per WORKSPACE: what the last prepare_conditioning on it was given -- the shape, n0 = leading batch entries with an all-zero context, pose_b.
     // forward() takes n0 from the workspace it runs on (a host may alternate workspaces / batch shapes on one context) and refuses a
     // workspace whose conditioning was never prepared or was prepared for another batch / pose layout
-    std::map<const void*, std::tuple<int, int, int, int, int, int>> cond_of_ws;   // {B, h, w, L, n0, pose_b}
+    std::map<const void*, std::tuple<int, int, int, int, int, int, int>> cond_of_ws;   // {B, h, w, L, n0, pose_b, shared CFG halves}
     std::string err;
 };
 
@@ -175,6 +175,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         int64_t ldo = 0;   // 0: N (GEGLU / NCHW: N)
         const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles only)
         float ln_eps = 0.f;
+        int dup_rows = 0;   // pcdm_gemm_params.dup_rows
         int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
     };
     // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
@@ -211,7 +212,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.out2 = g.out2;
         p.ldo2 = g.ldo2;
         p.zero_rows = g.zero_rows;
-        const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : 0};
+        p.dup_rows = g.dup_rows;
+        const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : (g.dup_rows ? 2 : 0)};
         auto it = u->tiles.find(key);
         if (it != u->tiles.end()) {
             p.tile = it->second.first;
@@ -436,7 +438,7 @@ extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w,
     int n0 = zero_ctx_batches;
     if (n0 < 0 || n0 > B) return -1;
     if (n0 == B) n0 = B > 1 ? B - 1 : 0;
-    u->cond_of_ws[workspace] = std::make_tuple(B, h, w, L, n0, pose ? pose_b : 0);
+    u->cond_of_ws[workspace] = std::make_tuple(B, h, w, L, n0, pose ? pose_b : 0, 0);
     if (c.class_embed) {
         if (!class_labels) return -1;
         const PW *c1 = R.pw("class_embedding.linear_1"), *c2 = R.pw("class_embedding.linear_2");
@@ -472,6 +474,18 @@ extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w,
     return R.rc;
 }
 
+// The caller guarantees that, on this workspace, batch entries b and b + B/2 always carry the same x_in rows and the same pose feature (the
+// two classifier-free-guidance halves): conv_in, the first norm1 and the first conv1's contraction then run once for both
+// (pcdm_gemm_params.dup_rows).  Call after pcdm_unet_prepare_conditioning (which resets it to 0).
+extern "C" int pcdm_unet_set_shared_cfg_input(pcdm_unet* u, void* workspace, int shared) {
+    if (!u) return -1;
+    auto it = u->cond_of_ws.find(workspace);
+    if (it == u->cond_of_ws.end()) return -1;
+    if (shared && (std::get<0>(it->second) % 2 || getenv_off("PCDM_SHARE_CFG_PREFIX"))) shared = 0;
+    std::get<6>(it->second) = shared ? 1 : 0;
+    return 0;
+}
+
 // One UNet forward (pcdms_amd/unet.py::_forward_nhwc): x_in NHWC bf16 [B, h, w, conv_in.cin]; the timestep is t_dev[step_dev ? *step_dev : 0]
 // (device memory: graph-replayable); eps_out fp32 NCHW [B, out_channels, h, w].  prepare_conditioning must have run on this workspace.
 extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* t_dev, const int32_t* step_dev, int B, int h, int w, int L,
@@ -492,6 +506,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         return -1;
     }
     const int n0 = std::get<4>(cit->second);
+    const bool shared = std::get<6>(cit->second) != 0;   // the CFG halves share conv_in / the first norm1 / the first conv1's contraction
 
     // ---- 1. time / class embedding (ref :661-708)
     R.chk(pcdm_timestep_embedding(t_dev, step_dev, R.buf<float>("t_emb"), B, C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding");
@@ -510,17 +525,27 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     }
     const float* temb = R.buf<float>("temb");
 
+    auto chk_gn_half = [&](const void* x1, int C1, int Bs, int HW_, float e, const float* gamma, const float* beta) {
+        R.groupnorm(x1, C1, nullptr, 0, Bs, HW_, e, gamma, beta, 1, R.buf("gn"));
+    };
     auto resnet = [&](const std::string& p, const void* x1, int C1, const void* x2, int C2, int HW_, int hh, int ww, const std::string& out_name,
-                      bool gn_next) -> void* {   // gn_next: the next reader of the block's output is a GroupNorm (split-K reduce folded into it)
+                      bool gn_next, bool shared_in = false) -> void* {   // gn_next: the next reader of the block's output is a GroupNorm (split-K reduce folded into it)
         const PW *cv1 = R.pw(p + "conv1"), *cv2 = R.pw(p + "conv2");
         if (R.rc) return nullptr;
         const int cin = C1 + C2, cout = cv1->N, M = B * HW_;
-        R.groupnorm(x1, C1, x2, C2, B, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"), 1, R.buf("gn"));
         Run::G g;
         g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = hh; g.Wo = ww;
         g.rowvec = temb + toff.at(p); g.ldrv = temb_n; g.rows_per_batch = HW_;
-        g.defer = 2;
-        R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
+        if (shared_in) {   // the CFG halves still have the same x1: norm1 and conv1's contraction once, two epilogues
+            const int Bs = B / 2, Ms = Bs * HW_;
+            chk_gn_half(x1, C1, Bs, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"));
+            g.B = Bs; g.dup_rows = Ms;
+            R.gemm(R.buf("gn"), cin, Ms, cv1, R.buf("c1"), g);
+        } else {
+            R.groupnorm(x1, C1, x2, C2, B, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"), 1, R.buf("gn"));
+            g.defer = 2;
+            R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
+        }
         R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
         const void* res = x1;
         if (u->w.count(p + "conv_shortcut")) {
@@ -602,6 +627,11 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         Run::G g;
         g.conv = 1; g.B = B; g.Hi = h; g.Wi = w; g.Ho = h; g.Wo = w;
         if (pose_b > 0) { g.residual = R.buf("pose"); g.ldr = C0; g.res_mod = B * HW; }   // (prepare_conditioning wrote B entries)
+        if (shared) {
+            g.B = B / 2; g.dup_rows = (B / 2) * HW;
+            if (pose_b > 0) g.res_mod = g.dup_rows;
+            R.gemm(x_in, 0, (B / 2) * HW, R.pw("conv_in"), R.buf("skip0"), g);
+        } else
         R.gemm(x_in, 0, B * HW, R.pw("conv_in"), R.buf("skip0"), g);
         x = R.buf("skip0");
     }
@@ -614,10 +644,10 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         for (int j = 0; j < Lb; ++j) {
             const std::string nm = "d" + std::to_string(i) + "." + std::to_string(j), rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".";
             if (has_cross(c, i)) {
-                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r", true);
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r", true, shared && i == 0 && j == 0);
                 x = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, ci, c.heads[i], hh * ww, nm);
             } else {
-                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm, j < Lb - 1 || i == n - 1);
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm, j < Lb - 1 || i == n - 1, shared && i == 0 && j == 0);
             }
             skips.push_back({x, hh, ww, ci});
         }

@@ -232,7 +232,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
-         defer_reduce: Optional[bool] = None) -> Union[torch.Tensor, "DeferredGemm"]:
+         defer_reduce: Optional[bool] = None, dup_rows: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
@@ -244,7 +244,10 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     ``defer_reduce`` (``True``: the reduced tensor is also read by something other than the next GroupNorm -- it gets written by that
     GroupNorm; ``False``-but-not-``None`` i.e. ``0``: only the next GroupNorm reads it): when the configuration in use splits K, skip the
     reduce launch and return a ``DeferredGemm`` for ``ops.groupnorm`` to consume.  The caller promises that the very next user of the
-    result is that GroupNorm and that no other split-K GEMM runs in between.  ``None``: never defer."""
+    result is that GroupNorm and that no other split-K GEMM runs in between.  ``None``: never defer.
+
+    ``dup_rows`` (conv only): ``out`` has ``M + dup_rows`` rows; rows ``m + dup_rows`` get the same contraction with THEIR row-vector /
+    residual rows (``pcdm_gemm_params.dup_rows``: the CFG-shared prefix of the UNet)."""
     if ln is not None and conv is None and a2 is None and ln_buf is not None:
         return _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0,
                         tile=tile)
@@ -287,6 +290,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     p.epilogue = epilogue
     p.act = act
     p.zero_rows = zero_rows   # (linear) A rows < zero_rows are declared all-zero: never read
+    p.dup_rows = dup_rows
+    assert not dup_rows or (conv is not None and out.shape[0] >= M + dup_rows)
     p.vt_col0 = vt_col0
     p.out = _ptr(out)
     p.ldo = out.stride(0) if (out.dim() == 2 and epilogue != EPI_NCHW_F32) else pw.N
@@ -297,7 +302,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     split = 1
     if tile == 0 and AUTOTUNE:
         key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
-               a2 is not None, residual is not None) + ((True,) if zero_rows else ())   # (w_ld does not change the best tile)
+               a2 is not None, residual is not None) + ((True,) if zero_rows else ((2,) if dup_rows else ()))   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
         if tile == 0 and a.is_cuda and not torch.cuda.is_current_stream_capturing():   # (the emulator build runs the library's heuristic)
             tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device, out)

@@ -207,7 +207,8 @@ class Stage2_InpaintDiffusionPipeline:
         extra = self.prepare_extra_step_kwargs(generator, eta)
 
         lat = self._sample(lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, guidance_scale, guidance_rescale,
-                           eta, extra, mode, use_graph, callback, callback_steps, zero_uncond=do_cfg)   # uncond context = literal zeros (:457-458)
+                           eta, extra, mode, use_graph, callback, callback_steps, zero_uncond=do_cfg,   # uncond context = literal zeros (:457-458)
+                           shared_halves=do_cfg)   # latents doubled (:499), one mask / masked latents / pose for both CFG halves (:430-459)
 
         images = self._postprocess(lat, output_type)
         if not return_dict:
@@ -215,9 +216,11 @@ class Stage2_InpaintDiffusionPipeline:
         return Stage2_InpaintDiffusionPipelineOutput(images=images, nsfw_content_detected=None, latents=lat)
 
     def _sample(self, lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, guidance_scale, guidance_rescale, eta,
-                extra, mode, use_graph, callback, callback_steps, zero_uncond=False):
+                extra, mode, use_graph, callback, callback_steps, zero_uncond=False, shared_halves=False):
         """The denoise loop on prepared (CFG-doubled) conditioning: fused + hipGraph for DDIM, the reference's literal loop otherwise.
-        ``zero_uncond``: the unconditional half of ``feature_f`` is literal zeros (the UNet then skips that half of every cross-attention)."""
+        ``zero_uncond``: the unconditional half of ``feature_f`` is literal zeros (the UNet then skips that half of every cross-attention).
+        ``shared_halves``: mask / masked latents / pose of the two CFG halves are the same tensors repeated (the UNet then runs conv_in,
+        the first norm1 and the first conv1's contraction once for both: ``prepare_conditioning(shared_cfg_input=True)``)."""
         linear = isinstance(self.scheduler, (DDIMScheduler, DDPMScheduler)) and eta == 0.0 \
             and not isinstance(self.scheduler, DDPMScheduler)
         # UniPC (ref stage2_batchtest_inpaint_model.py:132): multistep, but still one linear map per step on static state slots
@@ -251,7 +254,7 @@ class Stage2_InpaintDiffusionPipeline:
         else:
             lat = self._run_fused(lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg,
                                   float(guidance_scale), eta, use_graph, callback, callback_steps,
-                                  float(guidance_rescale) if do_cfg else 0.0, zero_uncond)
+                                  float(guidance_rescale) if do_cfg else 0.0, zero_uncond, shared_halves and do_cfg)
 
         return lat
 
@@ -299,7 +302,7 @@ class Stage2_InpaintDiffusionPipeline:
                 st[k].zero_()
 
     def _run_fused(self, lat, mask, masked, pose_cond, feature_f, prior_embed, timesteps, do_cfg, g, eta, use_graph,
-                   callback, callback_steps, guidance_rescale=0.0, zero_uncond=False):
+                   callback, callback_steps, guidance_rescale=0.0, zero_uncond=False, shared_halves=False):
         unet, dev = self.unet, self.device
         if unet._w is None:
             unet._pack()
@@ -310,7 +313,7 @@ class Stage2_InpaintDiffusionPipeline:
         n0 = N if (do_cfg and zero_uncond) else 0
         unipc = isinstance(self.scheduler, UniPCMultistepScheduler)
         key = (B, h, w, n, rep, n0, tuple(feature_f.shape), None if mask is None else tuple(mask.shape), tuple(masked.shape),
-               None if pose_cond is None else tuple(pose_cond.shape), prior_embed is None, unipc)
+               None if pose_cond is None else tuple(pose_cond.shape), prior_embed is None, unipc, bool(shared_halves))
         st = self._st if self._graph_key == key else {}
         if not st:
             st.update(B=B, h=h, w=w, rep=rep, unipc=unipc,
@@ -332,7 +335,7 @@ class Stage2_InpaintDiffusionPipeline:
         if mask is not None:
             st["mask"].copy_(mask)
         st["masked"].copy_(masked)
-        st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
+        st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0, shared_cfg_input=shared_halves)
         st["timesteps"].copy_(timesteps.to(dev))
         st["coef"].copy_(self.scheduler.coefficient_table(device=dev) if unipc else self.scheduler.coefficient_table(eta, device=dev))
         st["g"] = g
@@ -362,7 +365,8 @@ class Stage2_InpaintDiffusionPipeline:
                 self._zero_history(st)
                 self._ctx.sync_tiles()
                 st["c_tuned"] = (id(self._ctx), w_gen)
-            st["pose_b"] = self._ctx.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0)
+            st["pose_b"] = self._ctx.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0,
+                                                          shared_cfg_input=st["cond"].shared_halves)
             st["eps_c"] = st.get("eps_c") if st.get("eps_c") is not None and st["eps_c"].shape[0] == B else \
                 torch.empty(B, unet.config.out_channels, h, w, dtype=torch.float32, device=dev)
             st["ctx"] = self._ctx
@@ -510,7 +514,7 @@ class PCDMsPipeline(Simple_Stage2_InpaintDiffusionPipeline):
             def cb(i, t, cur):
                 callback_on_step_end(self, i, t, {"latents": cur})
         lat = self._sample(lat, mask_t, masked, pose_cond, feature_f.contiguous(), None, ts, do_cfg, guidance_scale, guidance_rescale, eta,
-                           extra, mode, use_graph, cb, 1)
+                           extra, mode, use_graph, cb, 1, shared_halves=do_cfg)   # (per_sample above: the same tensors for both halves)
         images = self._postprocess(lat, output_type)
         if not return_dict:
             return (images, None)

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import json
 import math
+import os
 from pathlib import Path
 from types import SimpleNamespace
 from typing import Any, Dict, Iterator, List, Optional, Tuple, Union
@@ -29,6 +30,8 @@ import torch
 from . import ops
 from ._module import ModuleSurface
 from .ops import BF16, PackedWeight
+
+SHARE_CFG_PREFIX = os.environ.get("PCDM_SHARE_CFG_PREFIX", "1") != "0"   # A/B switch (tools/README.md)
 
 _DEFAULT_CONFIG: Dict[str, Any] = dict(
     sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
@@ -95,11 +98,12 @@ def _as_tuple(v, n):
 class Conditioning:
     """Step-invariant part of one sampling call (``prepare_conditioning``): views of the model's scratch buffers."""
 
-    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv")
+    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv", "shared_halves")
 
     def __init__(self, gen: int, B: int, h: int, w: int, L: int):
         self.gen, self.B, self.h, self.w, self.L = gen, B, h, w, L
         self.n0 = 0                      # leading batch entries with an all-zero context (cross-attention skipped there)
+        self.shared_halves = False       # batch entries b and b + B/2 have the same sample / mask / masked latents / pose (the CFG halves)
         self.cls_emb: Optional[torch.Tensor] = None
         self.pose_nhwc: Optional[torch.Tensor] = None
         self.kv: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -383,7 +387,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
     # ------------------------------------------------------------------ step-invariant conditioning
     def prepare_conditioning(self, B: int, h: int, w: int, encoder_hidden_states: torch.Tensor,
                              class_labels: Optional[torch.Tensor], my_pose_cond: Optional[torch.Tensor],
-                             zero_ctx_batches: Optional[int] = None) -> "Conditioning":
+                             zero_ctx_batches: Optional[int] = None, shared_cfg_input: bool = False) -> "Conditioning":
         """Everything of one forward that does not depend on the timestep or the latents:
         class embedding (ref :688-708), NHWC pose feature (ref :742) and the cross-attention K / V^T of the context for all
         16 transformer blocks.  Results live in shape-keyed scratch buffers (static addresses: a captured hipGraph stays valid
@@ -393,7 +397,13 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         ``zero_ctx_batches`` = n0: the first n0 batch entries of ``encoder_hidden_states`` are all-zero (the CFG
         unconditional half, ref stage2_inpaint_pipeline.py:457-458).  ``to_k`` / ``to_v`` have no bias, so K = V = 0 there and
         the attention output is exactly 0, i.e. ``attn2(x) == to_out.0.bias``: those rows skip
-        LayerNorm-2, ``to_q``, the attention and the ``to_out`` contraction.  ``None`` = find out (one device reduction + sync)."""
+        LayerNorm-2, ``to_q``, the attention and the ``to_out`` contraction.  ``None`` = find out (one device reduction + sync).
+
+        ``shared_cfg_input``: the caller guarantees that batch entries b and b + B/2 will always carry the SAME ``sample`` and the same
+        pose feature -- the two classifier-free-guidance halves (ref stage2_inpaint_pipeline.py:499-501: ``torch.cat([latents] * 2)``,
+        one mask / masked latents / pose for both).  Only ``class_labels`` and the context differ between them, and those enter behind
+        ``conv_in``, the first GroupNorm and the contraction of the first ``conv1``: that prefix is then computed for B/2 entries and
+        written for both halves (``pcdm_gemm_params.dup_rows``) -- the same arithmetic, executed once."""
         if self._w is None:
             self._pack()
         W, cfg, dev = self._w, self.config, self._device
@@ -405,6 +415,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         L = ehs.shape[1]
         self._cond_gen += 1
         cond = Conditioning(gen=self._cond_gen, B=B, h=h, w=w, L=L)
+        cond.shared_halves = bool(shared_cfg_input) and B % 2 == 0 and B >= 2 and SHARE_CFG_PREFIX
         if cfg.class_embed_type == "projection":
             if class_labels is None:
                 raise ValueError("class_labels should be provided when num_class_embeds > 0")
@@ -562,15 +573,22 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         # loads its slab (ops.DeferredGemm / pcdm_groupnorm_splitk): no reduce launch, no bf16 round trip in front of the norm.  The bf16
         # tensor itself is written by that norm where a residual, shortcut or skip connection reads it later (`gn_next`: the caller
         # knows whether the next consumer of the block's output is a GroupNorm).
-        def resnet(p, x1, x2, HW_, hh, ww, name, gn_next=False):
+        def resnet(p, x1, x2, HW_, hh, ww, name, gn_next=False, shared=False):
             r = W[p]
             cin, cout, M = r["cin"], r["cout"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
-            n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
-            x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
-            cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
             tv = temb[:, r["toff"]: r["toff"] + cout]
-            h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False)
+            if shared:   # the CFG halves still have the same x1 here: norm1 and conv1's contraction once, two epilogues (temb rows b / b + B/2)
+                Bs, Ms = B // 2, (B // 2) * HW_
+                n1 = ops.groupnorm(x1[:Ms], None, Bs, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin))[:Ms], ws)
+                h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=dict(B=Bs, Hi=hh, Wi=ww, Ho=hh, Wo=ww), rowvec=tv,
+                              rows_per_batch=HW_, dup_rows=Ms)
+                cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
+            else:
+                n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
+                x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
+                cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
+                h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False)
             n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
@@ -619,9 +637,16 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
 
         # ---- 2. conv_in + pose (ref :742)
         HW = h * w
-        x = ops.gemm(x_in, W["conv_in"], self._buf("skip0", (B * HW, boc[0])), conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w),
-                     residual=None if pose_nhwc is None else pose_nhwc.view(-1, boc[0]),
-                     res_mod=0 if pose_nhwc is None else pose_nhwc.shape[0] * HW)
+        shared = cond.shared_halves   # the CFG halves share conv_in (+ pose), the first norm1 and the first conv1's contraction
+        if shared:
+            Mh = (B // 2) * HW
+            x = ops.gemm(x_in[: B // 2], W["conv_in"], self._buf("skip0", (B * HW, boc[0])), conv=dict(B=B // 2, Hi=h, Wi=w, Ho=h, Wo=w),
+                         residual=None if pose_nhwc is None else pose_nhwc.view(-1, boc[0])[:Mh], res_mod=0 if pose_nhwc is None else Mh,
+                         dup_rows=Mh)
+        else:
+            x = ops.gemm(x_in, W["conv_in"], self._buf("skip0", (B * HW, boc[0])), conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w),
+                         residual=None if pose_nhwc is None else pose_nhwc.view(-1, boc[0]),
+                         res_mod=0 if pose_nhwc is None else pose_nhwc.shape[0] * HW)
         # ---- 3. down (ref :746-761)
         skips: List[Tuple[torch.Tensor, int, int]] = [(x, h, w)]
         hh, ww = h, w
@@ -632,11 +657,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         for i, typ in enumerate(cfg.down_block_types):
             for j in range(L_):
                 nm = f"d{i}.{j}"
+                first = shared and i == 0 and j == 0
                 if typ == "CrossAttnDownBlock2D":
-                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r", gn_next=True)
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r", gn_next=True, shared=first)
                     x = transformer(f"down_blocks.{i}.attentions.{j}.", x, hh * ww, nm)
                 else:   # the next consumer is a resnet's norm1 (same block, or the mid block) unless a downsampling conv follows
-                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm, gn_next=j < L_ - 1 or i == nlev - 1)
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm, gn_next=j < L_ - 1 or i == nlev - 1, shared=first)
                 skips.append((skip_of(x), hh, ww))
             if i != nlev - 1:
                 ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1

@@ -112,7 +112,7 @@ class UNetContext:
                 args = (1, M, Npad, K, 0, 0, 0, epi, 0, 0, 0)
             else:
                 M, Npad, K, conv, stride, ups, epi, two, res = key[:9]
-                args = (0, M, Npad, K, int(conv), int(stride), int(ups), epi, int(two), int(res), int(len(key) > 9))
+                args = (0, M, Npad, K, int(conv), int(stride), int(ups), epi, int(two), int(res), int(key[9]) if len(key) > 9 else 0)   # (1: zero_rows, 2: dup_rows)
             self._chk(_lib.lib().pcdm_unet_set_tile(self._h, *args, int(tile), int(split)), "pcdm_unet_set_tile")
             n += 1
         return n
@@ -133,7 +133,7 @@ class UNetContext:
     # ------------------------------------------------------------------ run
     @torch.no_grad()
     def prepare_conditioning(self, B: int, h: int, w: int, encoder_hidden_states: torch.Tensor, class_labels: Optional[torch.Tensor],
-                             my_pose_cond: Optional[torch.Tensor], zero_ctx_batches: int = 0) -> int:
+                             my_pose_cond: Optional[torch.Tensor], zero_ctx_batches: int = 0, shared_cfg_input: bool = False) -> int:
         """Returns ``pose_b`` (0 / 1 / B), which ``forward`` wants back."""
         dev = self.unet.device
         ehs = encoder_hidden_states.to(dev, torch.float32).contiguous()
@@ -145,6 +145,7 @@ class UNetContext:
         self._chk(_lib.lib().pcdm_unet_prepare_conditioning(self._h, B, h, w, L, ehs.data_ptr(), None if cl is None else cl.data_ptr(),
                                                             None if pose is None else pose.data_ptr(), pose_b, int(zero_ctx_batches),
                                                             ws.data_ptr(), ops._stream(ws)), "pcdm_unet_prepare_conditioning")
+        self._chk(_lib.lib().pcdm_unet_set_shared_cfg_input(self._h, ws.data_ptr(), int(bool(shared_cfg_input))), "pcdm_unet_set_shared_cfg_input")
         self._L = L
         return pose_b
 

@@ -874,3 +874,41 @@ def test_splitk_reduce_folded_into_groupnorm(backend, case):
         ref = torch.cat([ref, x2.float()], 1)
     gn = F.silu(F.group_norm(ref.view(B, HW, C).permute(0, 2, 1), G, gamma.cpu(), beta.cpu(), 1e-5)).permute(0, 2, 1)
     close(y.view(B, HW, C), gn, tol=2e-2)
+
+
+def test_conv_dup_rows_shared_cfg_prefix(backend):
+    """``pcdm_gemm_params.dup_rows`` (VERDICT r3 next-round #1a): one contraction of a 3x3 convolution, two epilogues -- the second writes
+    rows m + dup_rows with THEIR row-vector (time embedding) and residual rows.  Must be BIT-IDENTICAL to the same tile configuration run
+    on the doubled batch (the two CFG halves carry the same input), for conv_in's form (+ residual) and conv1's (+ bias + temb row)."""
+    dev = backend.device
+    for (Bh, H, Wd, Cin, Cout, tiles, form) in ([(1, 6, 8, 64, 64, (2, 5), "temb"), (2, 4, 8, 64, 128, (2, 4), "res")] if backend.is_emu else
+                                                [(4, 64, 88, 320, 320, (21, 5, 11), "temb"), (4, 64, 88, 64, 320, (21, 10), "res"),
+                                                 (3, 13, 11, 128, 192, (2, 5), "temb")]):
+        HW, Mh = H * Wd, Bh * H * Wd
+        if form == "temb" and HW < 32:
+            continue
+        x = rnd(Bh, H, Wd, Cin, seed=301)
+        w = rnd(Cout, Cin, 3, 3, seed=302, scale=1 / math.sqrt(9 * Cin))
+        bias = torch.randn(Cout, generator=torch.Generator().manual_seed(303))
+        temb = torch.randn(2 * Bh, Cout, generator=torch.Generator().manual_seed(304)).to(dev) if form == "temb" else None
+        res = rnd(2 * Mh, Cout, seed=305).to(dev) if form == "res" else None
+        pw = ops.pack_conv3x3(w.float(), bias, dev)
+        x2 = torch.cat([x, x]).to(dev)                      # the doubled batch: both halves the same input
+        for tile in tiles:
+            if pw.Npad % ops.TILE_SHAPES[tile][1]:
+                continue
+            kw_full, kw_dup = dict(tile=tile), dict(tile=tile, dup_rows=Mh)
+            if temb is not None:
+                kw_full.update(rowvec=temb, rows_per_batch=HW); kw_dup.update(rowvec=temb, rows_per_batch=HW)
+            if res is not None:
+                kw_full.update(residual=res, res_mod=2 * Mh); kw_dup.update(residual=res[:Mh], res_mod=Mh)
+            ref = torch.empty(2 * Mh, Cout, dtype=BF16, device=dev)
+            ops.gemm(x2, pw, ref, conv=dict(B=2 * Bh, Hi=H, Wi=Wd, Ho=H, Wo=Wd), **kw_full)
+            out = torch.full((2 * Mh, Cout), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(x2[:Bh], pw, out, conv=dict(B=Bh, Hi=H, Wi=Wd, Ho=H, Wo=Wd), **kw_dup)
+            backend.sync()
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (form, tile, (out.float() - ref.float()).abs().max())
+    # refused where the lean epilogue cannot take it: linear, split-K, an activation
+    pwl = ops.pack_linear(rnd(64, 64, seed=1).float(), None, dev)
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm(rnd(64, 64, seed=2).to(dev), pwl, torch.empty(128, 64, dtype=BF16, device=dev), dup_rows=64, tile=2)

@@ -381,3 +381,45 @@ def test_cross_attention_skip_is_exact(backend):
     assert m.prepare_conditioning(B, h, w, ehs2, cl, pose).n0 == 0
     with pytest.raises(RuntimeError):   # the earlier Conditioning is stale now
         m._forward_nhwc(x_in(), B, h, w, t, cond)
+
+
+def test_cfg_shared_prefix_in_the_sampler(backend, monkeypatch):
+    """The stage-2 sampler tells the UNet that its two CFG halves share sample / mask / masked latents / pose (the reference doubles one
+    tensor, stage2_inpaint_pipeline.py:457-459, 499-501): conv_in, the first norm1 and the first conv1's contraction then run once.  The
+    sampled latents equal those of the unshared schedule (``PCDM_SHARE_CFG_PREFIX=0``) up to the tile choice of the half-batch launches
+    (bit-exactness at fixed tiles: tests/test_unet_ctx.py::test_cfg_shared_prefix_is_exact).  Stage 3 -- whose unconditional half has
+    ZERO refine latents (stage3_refined_pipeline.py:491-497), i.e. a different UNet input -- must not share."""
+    import pcdms_amd.unet as U
+    from pcdms_amd.pipeline import Stage3_RefinedDiffusionPipeline
+    from pcdms_amd.unet import UNet2DConditionModel
+    cfg = UNetConfig.tiny()
+    dev = backend.device
+    N, h, w, L, steps = (1, 8, 8, 4, 1) if backend.is_emu else (2, 16, 24, 9, 4)
+    sd, m = _build(backend, cfg)
+    inp = synth_inputs(cfg, h, w, N, L_img=L)
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    a = _call(pipe, inp, dev, N, steps, h, w)
+    assert pipe._st["cond"].shared_halves
+    monkeypatch.setattr(U, "SHARE_CFG_PREFIX", False)
+    pipe2 = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    b = _call(pipe2, inp, dev, N, steps, h, w)
+    assert not pipe2._st["cond"].shared_halves
+    backend.sync()
+    assert _same_path(a, b, steps_are_one=False), _rel(a, b.float().cpu())
+    monkeypatch.setattr(U, "SHARE_CFG_PREFIX", True)
+    # without CFG there are no halves
+    c = _call(pipe, inp, dev, N, steps, h, w, guidance_scale=1.0)
+    assert not pipe._st["cond"].shared_halves and bool(torch.isfinite(c).all())
+    if backend.is_emu:
+        return
+    # stage 3: the uncond half's refine latents are zero -> different conv_in input -> never shared
+    c3 = UNetConfig.tiny(in_channels=8, class_embed_type=None, projection_class_embeddings_input_dim=None)
+    m3 = UNet2DConditionModel(**_kwargs(c3))
+    m3.load_state_dict(synth_state_dict(c3, seed=5, random_affine=True))
+    m3.to(dev)
+    p3 = Stage3_RefinedDiffusionPipeline(m3, DDIMScheduler.from_config(SD21))
+    g = torch.Generator().manual_seed(3)
+    p3(height=h * 8, width=w * 8, num_inference_steps=2, guidance_scale=2.0, num_images_per_prompt=N, output_type="latent",
+       s_img_proj_f=torch.randn(1, L, c3.cross_attention_dim, generator=g).to(dev), gen_t_img_latents=torch.randn(1, 4, h, w, generator=g).to(dev),
+       latents=torch.randn(N, 4, h, w, generator=g).to(dev))
+    assert not p3._st["cond"].shared_halves

@@ -209,3 +209,60 @@ def test_splitk_deferral_through_both_schedules(backend, monkeypatch):
     assert torch.equal(ref_py, ref_c)
     assert torch.equal(out_py, ref_py), (out_py - ref_py).abs().max()
     assert torch.equal(out_c, ref_py), (out_c - ref_py).abs().max()
+
+
+def test_cfg_shared_prefix_is_exact(backend, monkeypatch):
+    """The CFG-shared prefix (``prepare_conditioning(shared_cfg_input=True)`` / ``pcdm_unet_set_shared_cfg_input``): with both halves of
+    the batch carrying the same sample and pose, conv_in, the first norm1 and the first conv1's contraction run once for B/2 entries and
+    are written for both halves.  With the half-batch problems held to the tile configuration of the full-batch ones the forward must
+    equal the unshared forward BIT FOR BIT, in the Python schedule and in ``pcdm_unet_forward``; a sample that differs between the halves
+    must NOT be shared (the flag is the caller's promise) -- checked by the pipeline-level test in tests/test_pipeline.py."""
+    cfg = UNetConfig.tiny()
+    dev = backend.device
+    B, h, w, L, n0 = (2, 8, 8, 5, 1) if backend.is_emu else (8, 16, 24, 9, 4)
+    sd = synth_state_dict(cfg, seed=3, random_affine=True)
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(dev)
+    g = torch.Generator().manual_seed(0)
+    s_half = torch.randn(B // 2, cfg.in_channels, h, w, generator=g)
+    s = torch.cat([s_half, s_half])                                       # both CFG halves: the same sample
+    e = torch.randn(B, L, cfg.cross_attention_dim, generator=g)
+    e[:n0] = 0
+    c = torch.randn(B, 1, cfg.projection_class_embeddings_input_dim, generator=g) * 0.4     # class labels DIFFER between the halves
+    p = torch.randn(1, cfg.block_out_channels[0], h, w, generator=g) * 0.1
+    t = torch.tensor([417], dtype=torch.int64, device=dev)
+    x_in = ops.nchw_to_nhwc_bf16(s.to(dev), cpad=m._w["conv_in"].cin) if m._w else None
+    if x_in is None:
+        m._pack()
+        x_in = ops.nchw_to_nhwc_bf16(s.to(dev), cpad=m._w["conv_in"].cin)
+
+    class Rec(dict):
+        seen: list = []
+
+        def get(self, k, d=None):
+            self.seen.append(k)
+            return super().get(k, d)
+    rec = Rec(ops._TUNED)
+    monkeypatch.setattr(ops, "_TUNED", rec)
+
+    def run(shared):
+        cond = m.prepare_conditioning(B, h, w, e.to(dev), c.to(dev), p.to(dev), zero_ctx_batches=n0, shared_cfg_input=shared)
+        assert cond.shared_halves == shared
+        a = m._forward_nhwc(x_in, B, h, w, t, cond).clone()
+        ctx = UNetContext(m)
+        pose_b = ctx.prepare_conditioning(B, h, w, e, c, p, zero_ctx_batches=n0, shared_cfg_input=shared)
+        b = ctx.forward(x_in, t, None, B, h, w, pose_b)
+        backend.sync()
+        return a, b
+    run(False); run(True)                                                  # record (and, on the GPU, tune) every problem key of both forms
+    dup_keys = [k for k in set(rec.seen) if isinstance(k[0], int) and len(k) > 9 and k[9] == 2]
+    assert len(dup_keys) == 2, dup_keys                                    # conv_in and the first conv1
+    for k in dup_keys:                                                     # the half-batch problems on the tile of their full-batch twins
+        full = (2 * k[0],) + k[1:9]
+        dict.__setitem__(rec, full, (5, 1))
+        dict.__setitem__(rec, k, (5, 1))
+    ref_py, ref_c = run(False)
+    out_py, out_c = run(True)
+    assert torch.equal(ref_py, ref_c) and torch.equal(out_py, out_c)
+    assert torch.equal(out_py, ref_py), (out_py - ref_py).abs().max()
