@@ -195,7 +195,7 @@ def main():
         result["roofline"]["e2e_frac_executed"] = round(ex_tflops / PEAK_BF16_TFLOPS, 4)
         result["config"]["e2e_tflops_per_gpu_executed"] = round(ex_tflops, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (other ranks would idle)
-        result["cpu_baseline"] = cpu_baseline(sd, cfg, inp, N, args.ddim_steps)
+        result["cpu_baseline"] = cpu_baseline(N, args.ddim_steps)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -340,59 +340,141 @@ def kernel_source_hash() -> str:
     return hsh.hexdigest()
 
 
-def cpu_baseline(sd, cfg, inp, N, ddim_steps):
-    """The fp32 PyTorch CPU restatement (oracle/) timed on this box's host cores.  Substitute for the reference's CPU diffusers
-    path, which cannot run (diffusers is not installed / vendored).  Two records:
-      * ``value``: configs[1] on a bounded sample -- 1 timed denoise step (UNet batch 2N at the full latent size + CFG + DDIM
-        update; the configs[0] run before it serves as warm-up), extrapolated to the 50-step call;
-      * ``config1``: BASELINE.json configs[0] in FULL -- one 256x256 pair (canvas 512x256, latent 32x64), N = 1, 20 DDIM steps,
-        guidance 2.0, fp32: wall seconds of the whole sampling loop (SURVEY.md §8d "config 1")."""
+def cpu_baseline(N, ddim_steps):
+    """The fp32 PyTorch CPU restatement (oracle/) timed on this box's host cores -- substitute for the reference's CPU diffusers path,
+    which cannot run (diffusers is not installed / vendored).  Timed in a CHILD process so that the OpenMP runtime starts
+    pinned: ``OMP_PROC_BIND=close`` with explicit ``OMP_PLACES`` = one place per physical core, the cores of NUMA node 0
+    first (then the following nodes) -- unpinned threads migrating across NUMA domains were why 64 threads measured slower than 32 in round 3.
+      * ``value``: a BOUNDED sample of configs[1] -- one denoise step (UNet forward at the full latent size + CFG + DDIM update) for ONE
+        generated image (UNet batch 2), 1 warm-up + 2 timed steps per thread count (8 / 32 / 64 where the host has them), the best count
+        extrapolated to the 50-step call; images/s per process;
+      * ``config1``: BASELINE.json configs[0] in FULL -- one 256x256 pair (latent 32x64), N = 1, 20 DDIM steps, guidance 2.0, fp32."""
+    import subprocess
+    topo = host_topology()
+    counts = sorted({c for c in (8, 32, 64) if c <= topo["physical_cores"]} | {min(8, topo["physical_cores"])})
+    # explicit places, one per physical core, NUMA node 0's cores first: thread i of the child's OpenMP team is bound to cpus[i], so a
+    # run with n threads uses exactly the first n cores of that order (computed HERE: once OMP_PROC_BIND is in the environment the
+    # child's own main thread is already bound to one CPU when it could look)
+    cpus = pinned_cpu_order(topo)[: max(counts)]
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES=",".join("{%d}" % c for c in cpus), OMP_NUM_THREADS=str(max(counts)),
+               MKL_NUM_THREADS=str(max(counts)), PCDM_CPU_BASELINE_COUNTS=",".join(map(str, counts)), PCDM_CPU_BASELINE_STEPS=str(ddim_steps),
+               PCDM_CPU_BASELINE_CPUS=",".join(map(str, cpus)), PCDM_CPU_BASELINE_TOPO=json.dumps(topo))
+    env.pop("HIP_VISIBLE_DEVICES", None)
+    try:
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-worker"], env=env, capture_output=True, text=True, timeout=900)
+        doc = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # the GPU line must not die with the host leg
+        return {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"CPU baseline worker failed: {e!r}", "host": topo}
+    per = {int(k): v for k, v in doc["per_thread_count"].items()}
+    best = min(per, key=lambda n: per[n]["s_per_step"])
+    per_step = per[best]["s_per_step"]
+    return {"value": round(1.0 / (per_step * ddim_steps), 5), "unit": "images/s", "cores": best, "kind": "port",
+            "sample": f"one denoise step of configs[1] for ONE generated image (UNet batch 2, latent 64x88, fp32, torch {torch.__version__} CPU ops, attention through F.scaled_dot_product_attention as diffusers 0.24 does): "
+                      f"1 warm-up + 2 timed steps per thread count, threads pinned one per physical core (OMP_PROC_BIND=close, explicit OMP_PLACES, NUMA node 0's cores first); {per_step:.2f} s/step at {best} threads, extrapolated x{ddim_steps}",
+            "host": doc["host"], "per_thread_count": doc["per_thread_count"], "config1": doc["config1"],
+            "note": "a reported baseline, not a target: one host process; the GPU line is whole-job throughput of N images per call"}
+
+
+def cpu_baseline_worker():
+    """Child of ``cpu_baseline`` (``bench.py --cpu-baseline-worker``): its OpenMP team is placed by the environment the parent built."""
+    topo = json.loads(os.environ["PCDM_CPU_BASELINE_TOPO"]) if "PCDM_CPU_BASELINE_TOPO" in os.environ else host_topology()
+    counts = [int(c) for c in os.environ.get("PCDM_CPU_BASELINE_COUNTS", "8").split(",")]
+    ddim_steps = int(os.environ.get("PCDM_CPU_BASELINE_STEPS", "50"))
+    cpus = [int(c) for c in os.environ.get("PCDM_CPU_BASELINE_CPUS", "0").split(",")]   # (the parent's placement: OMP_PLACES)
     from oracle.pipeline import build_conditioning, stage2_sample, synth_inputs
     from oracle.schedulers import DDIMOracle
-    from oracle.unet import unet_forward
-    topo = host_topology()
+    import oracle.unet as OU
+    from oracle.unet import UNetConfig, synth_state_dict, unet_forward
+    OU.ATTENTION_IMPL = "sdpa"   # what diffusers 0.24 runs on torch >= 2 (AttnProcessor2_0); the explicit-softmax form is the parity checker's
+    cfg = UNetConfig()
+    torch.set_num_threads(max(counts))
+    sd = synth_state_dict(cfg, seed=0)
+    N, h, w = 1, 64, 88
+    inp = synth_inputs(cfg, h, w, N)
     c = build_conditioning(inp["masked_latents"], inp["s_img_proj_f"], inp["st_pose_f"], inp["pred_t_img_embed"], N, True)
     sch = DDIMOracle()
     sch.set_timesteps(ddim_steps)
     lat = inp["latents"].clone()
-    threads_before = torch.get_num_threads()
-    # thread counts to time (SURVEY.md §8d): the PHYSICAL cores of one socket, and half of them.  torch's default is the number of
-    # LOGICAL CPUs (round 2 timed 128 threads on a 2 x 32-core box: hyper-threads and the second socket's memory made the fp32 GEMMs
-    # ~4x slower than 8 threads on 8 cores).  `value` / `cores` are the better of the two.
-    # (measured on the 2 x 64-core driver box: 64 threads 27.5 s per step, 128 threads 41.8 s -- more threads are SLOWER there)
-    counts = sorted({max(1, topo["cores_per_socket"] // 2), topo["cores_per_socket"]})
 
-    def one_step(nthreads):
-        torch.set_num_threads(nthreads)
+    def one_step():
         t = sch.timesteps[0]
         t0 = time.perf_counter()
         x = torch.cat([lat] * 2)
-        eps = unet_forward(sd, cfg, torch.cat([x, c["mask"], c["masked_latents"]], 1), t, c["feature_f"],
-                           c["prior_embed"], c["pose_cond"])
+        eps = unet_forward(sd, cfg, torch.cat([x, c["mask"], c["masked_latents"]], 1), t, c["feature_f"], c["prior_embed"], c["pose_cond"])
         u, cn = eps.chunk(2)
         out = sch.step(u + 2.0 * (cn - u), t, lat)
         assert torch.isfinite(out).all()
         return time.perf_counter() - t0
+    per = {}
     with torch.no_grad():
-        # configs[0] first: it also warms the host thread pool / primitive caches for the full-size step that follows
-        torch.set_num_threads(counts[0])
+        for n in counts:
+            torch.set_num_threads(n)                     # the first n places
+            one_step()                                   # warm-up (thread pool, primitive caches)
+            ts = [one_step(), one_step()]
+            v = min(ts)
+            per[str(n)] = {"s_per_step": round(v, 3), "s_per_step_both": [round(x, 3) for x in ts], "images_per_s": round(1.0 / (v * ddim_steps), 5),
+                           "tflops_fp32": round(2 * N * FLOP_PER_ROW_FWD / v / 1e12, 3)}
+        best = min(per, key=lambda k: per[k]["s_per_step"])
+        torch.set_num_threads(int(best))
         inp1 = synth_inputs(cfg, 32, 64, 1)
         t0 = time.perf_counter()
         out1 = stage2_sample(sd, cfg, DDIMOracle(), num_images_per_prompt=1, guidance_scale=2.0, num_inference_steps=20, **inp1)
         c1_s = time.perf_counter() - t0
-        per = {n: one_step(n) for n in counts}
-    torch.set_num_threads(threads_before)
     assert torch.isfinite(out1).all()
-    best = min(per, key=per.get)
-    per_step = per[best]
-    return {"value": round(N / (per_step * ddim_steps), 5), "unit": "images/s", "cores": best, "kind": "port",
-            "sample": f"1 timed denoise step (after the configs[0] run as warm-up) of the same workload (UNet batch {2 * N}, fp32, "
-                      f"torch {torch.__version__} CPU ops) per thread count, {per_step:.2f} s/step at {best} threads, extrapolated x{ddim_steps}",
-            "host": topo,
-            "per_thread_count": {str(n): {"s_per_step": round(v, 2), "images_per_s": round(N / (v * ddim_steps), 5),
-                                          "tflops_fp32": round(2 * N * FLOP_PER_ROW_FWD / v / 1e12, 3)} for n, v in per.items()},
-            "config1": {"workload": "configs[0]: 1 pair 256x256 (latent 32x64), N=1, 20 DDIM steps, guidance 2.0, fp32 CPU, full run",
-                        "threads": counts[0], "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}
+    topo["numa_nodes"] = numa_nodes()
+    topo["pinned_cpus_first16"] = cpus[:16]
+    print(json.dumps({"host": topo, "per_thread_count": per,
+                      "config1": {"workload": "configs[0]: 1 pair 256x256 (latent 32x64), N=1, 20 DDIM steps, guidance 2.0, fp32 CPU, full run",
+                                  "threads": int(best), "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}), flush=True)
+
+
+def numa_nodes():
+    """{node: cpulist string} from sysfs (what ``numactl -H`` prints)."""
+    out = {}
+    base = Path("/sys/devices/system/node")
+    if base.exists():
+        for d in sorted(base.glob("node[0-9]*")):
+            try:
+                out[d.name] = (d / "cpulist").read_text().strip()
+            except OSError:
+                pass
+    return out
+
+
+def _parse_cpulist(txt):
+    cpus = []
+    for part in txt.split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pinned_cpu_order(topo):
+    """Logical CPUs in the order the baseline's threads take them: ONE hyper-thread per physical core, NUMA node 0's cores first, then
+    the other nodes in order (node numbering follows the sockets), restricted to this process's allowed set."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    order, seen_cores = [], set()
+    nodes = numa_nodes() or {"node0": ",".join(map(str, sorted(allowed)))}
+    for _, lst in sorted(nodes.items(), key=lambda kv: int(kv[0][4:])):
+        for cpu in _parse_cpulist(lst):
+            if cpu not in allowed:
+                continue
+            try:
+                sib = Path(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list").read_text().strip()
+                core = min(_parse_cpulist(sib))
+            except OSError:
+                core = cpu
+            if core in seen_cores:
+                continue
+            seen_cores.add(core)
+            order.append(cpu)
+    return order or sorted(allowed)
 
 
 def host_topology():
@@ -425,4 +507,7 @@ def host_topology():
 
 
 if __name__ == "__main__":
-    main()
+    if "--cpu-baseline-worker" in sys.argv:
+        cpu_baseline_worker()
+    else:
+        main()

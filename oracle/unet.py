@@ -217,6 +217,12 @@ def resnet_block(sd, p, x, emb, groups, eps):
     return x + h
 
 
+# "explicit": scores, softmax, PV as three fp32 tensor ops (the checker: every parity test).  "sdpa": the same mathematics through
+# F.scaled_dot_product_attention -- what the reference's CPU path runs (diffusers 0.24 installs AttnProcessor2_0 whenever torch has it)
+# and several times faster on a host (no 5632 x 5632 score tensors through memory): used by bench.py's CPU-baseline timing ONLY.
+ATTENTION_IMPL = "explicit"
+
+
 def attention(sd, p, x, ctx, heads):
     """Appendix A-7 ``Attention`` (no mask; scale = head_dim**-0.5)."""
     B, N, C = x.shape
@@ -228,8 +234,11 @@ def attention(sd, p, x, ctx, heads):
     q = q.view(B, N, heads, d).transpose(1, 2)
     k = k.view(B, -1, heads, d).transpose(1, 2)
     v = v.view(B, -1, heads, d).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.softmax(s, dim=-1) @ v
+    if ATTENTION_IMPL == "sdpa":   # timing only (bench.py's cpu_baseline): diffusers 0.24's default AttnProcessor2_0 on torch >= 2
+        o = F.scaled_dot_product_attention(q, k, v)
+    else:
+        s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.softmax(s, dim=-1) @ v
     o = o.transpose(1, 2).reshape(B, N, C)
     return _lin(sd, p + "to_out.0.", o)
 

@@ -415,6 +415,10 @@ __global__ __launch_bounds__(THREADS) void gn_fused_kernel(const GnSrc src, int 
 // in two launches.  The grid is at most one workgroup per CU, so all S partners are resident (no deadlock); the counters are
 // self-resetting (the last workgroup to have READ the partials clears them; the next launch cannot start before this one ends).
 // ws layout: [slab][S][4 groups][2] floats, then [slab][2] unsigned counters (arrived, read) -- zeroed once by the caller.
+// (Round 4 measured the alternative decomposition -- a workgroup owns whole ROWS of an image with all channels, 32 workgroups per image
+//  exchange every group's statistics: 640-byte accesses instead of 80-byte pieces -- at 24.2 us against this kernel's 24.0 us at level 0
+//  and 18.1 against 14.1 us at level 1 (profiles/r4_bench_gn_rows_ab.txt): the access granularity is not what bounds this kernel; the
+//  serial read -> exchange -> write structure is.  Dropped.)
 template <int THREADS, int MAXR, bool SK>
 __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, int B,
                                                             int HW, int gs, int gpb, int noct, int S, int rows_per_chunk, float eps,
@@ -564,195 +568,6 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, in
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float mean = stat[2 * (ge[e] & 3)], rstd = stat[2 * (ge[e] & 3) + 1];
-        sc[e] = rstd * gamma[c + e];
-        sh[e] = beta[c + e] - mean * sc[e];
-    }
-#pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-        const int r = r0 + rp + i * rows_par;
-        if (r < r1) {
-            u16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf2f(v[i][e]) * sc[e] + sh[e];
-                if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
-                o[e] = f2bf(f);
-            }
-            *(u16x8*)(y + ((int64_t)b * HW + r) * C + c) = o;
-        }
-    }
-}
-
-// ---- single-pass GroupNorm with ROW-wise ownership (round 4; UNet levels 0 / 1): a workgroup owns a chunk of ROWS of one image with ALL
-// its channels -- every global access is a whole C x 2-byte row (640 B .. 2.5 KiB contiguous), where gn_cluster_kernel's (image, group
-// set) slabs read 80-byte pieces of 640-byte rows (1.6 cache lines requested per 80 useful bytes: its 24 us at level 0 are 2.4 TB/s
-// against the 5.3 TB/s the LayerNorm kernel reaches on the same tensor with whole rows).  The price is a wider exchange: the S = 256 / B
-// workgroups of an image (32 at batch 8) publish {sum, sum of squares} of ALL groups for their rows, wait for each other, and every one
-// of them finishes the statistics of all groups itself (fixed order, fp64: bit-identical in every workgroup and run to run).  Same
-// hand-off protocol, counters, bounded poll and timeout counter as gn_cluster_kernel; a workgroup whose partners do not arrive
-// recomputes the other chunks' partial sums itself WITH THE SAME ARITHMETIC (so even the fallback is bit-identical -- which is also how
-// the lane emulator, where workgroups cannot wait for each other, runs this kernel: its poll gives up at once).
-// LDS: rows_par x C floats twice (cross-row reduce), the partners' partials.
-constexpr int kGnRowsMaxGroups = 64;
-template <int THREADS, int MAXR, bool SK>
-__global__ __launch_bounds__(THREADS) void gn_rows_kernel(const GnSrc src, int B, int HW, int groups, int gs, int S, int rows_per_chunk, float eps,
-                                                         double inv_n /* 1 / (HW * gs) */, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int fuse_silu, u16* __restrict__ y,
-                                                         float* __restrict__ part_all /* [B][S][groups][2] */, unsigned* __restrict__ cnt_all /* [B][2] */,
-                                                         unsigned* __restrict__ timeouts) {
-    PCDM_DYN_SMEM(smem);
-    const int C = src.C1 + src.C2, noct = C / 8;
-    const int rows_par = THREADS / noct;
-    float* red_s = (float*)smem;                       // [rows_par][C]
-    float* red_q = red_s + rows_par * C;               // [rows_par][C]
-    float* gsum = red_q + rows_par * C;                // [groups][2]: this chunk's per-group {sum, sum of squares}
-    float* pbuf = gsum + 2 * kGnRowsMaxGroups;         // [S][groups][2]: every chunk's
-    float* stat = pbuf + S * groups * 2;               // [groups][2] {mean, rstd}
-    __shared__ int stat_flag[1];
-    const int b = blockIdx.x % B, chunk = blockIdx.x / B;
-    const int t = threadIdx.x;
-    const int rp = t / noct, oc = t - rp * noct;
-    const bool active = rp < rows_par;
-    const int c = oc * 8;
-    const int r0 = chunk * rows_per_chunk;
-    const int r1 = (r0 + rows_per_chunk < HW) ? r0 + rows_per_chunk : HW;
-    u16x8 v[MAXR];
-#pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-        const int r = r0 + rp + i * rows_par;
-        const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        v[i] = (active && r < r1) ? gn_src_load<SK>(src, b, (int64_t)b * HW + r, c) : z;
-    }
-    if (SK && src.pre_out && active && c < src.C1) {
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const int r = r0 + rp + i * rows_par;
-            if (r < r1) *(u16x8*)(src.pre_out + ((int64_t)b * HW + r) * src.C1 + c) = v[i];
-        }
-    }
-    // per-group {sum, sum of squares} of the rows [ra, rb) of this image held as w[] (rows beyond the chunk are zeros): per-thread channel
-    // sums -> LDS -> per-channel over the row lanes (fixed order) -> per-group over its channels (fixed order) -> gsum
-    auto chunk_sums = [&](const u16x8 (&w)[MAXR]) {
-        float sc_[8], qc_[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sc_[e] = qc_[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = bf2f(w[i][e]);
-                sc_[e] += f;
-                qc_[e] += f * f;
-            }
-        __syncthreads();   // (previous use of red_* / gsum is over)
-        if (active) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red_s[rp * C + c + e] = sc_[e];
-                red_q[rp * C + c + e] = qc_[e];
-            }
-        }
-        __syncthreads();
-        for (int ch = t; ch < C; ch += THREADS) {
-            float a = 0.f, q = 0.f;
-            for (int j = 0; j < rows_par; ++j) {
-                a += red_s[j * C + ch];
-                q += red_q[j * C + ch];
-            }
-            red_s[ch] = a;          // (row 0 of the scratch now holds the per-channel totals: only thread ch touches column ch)
-            red_q[ch] = q;
-        }
-        __syncthreads();
-        if (t < groups) {
-            float a = 0.f, q = 0.f;
-            for (int k = t * gs; k < (t + 1) * gs; ++k) {
-                a += red_s[k];
-                q += red_q[k];
-            }
-            gsum[2 * t] = a;
-            gsum[2 * t + 1] = q;
-        }
-        __syncthreads();
-    };
-    chunk_sums(v);
-#pragma unroll
-    for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
-    // ---- publish, wait for the partners (bounded), collect everybody's partials
-    float* part = part_all + (int64_t)b * S * groups * 2;
-    unsigned* cnt = cnt_all + b * 2;
-    if (t < 2 * groups) pcdm_store_sys(part + chunk * groups * 2 + t, gsum[t]);
-    pcdm_drain_vmem();
-    __syncthreads();
-    if (t == 0) {
-        pcdm_atomic_inc_agent(cnt);
-        bool ok = true;
-#ifdef PCDM_EMU
-        ok = false;   // workgroups run one after the other under the lane emulator: take the self-sufficient path
-#else
-        unsigned spins = 0;
-        while (pcdm_load_sys_u32(cnt) < (unsigned)S) {
-            pcdm_sleep();
-            if (++spins > kGnSpinLimit) { ok = false; break; }
-        }
-        if (!ok) pcdm_atomic_inc_agent(timeouts);
-#endif
-        stat_flag[0] = ok ? 0 : 1;
-    }
-    __syncthreads();
-    const bool alone = stat_flag[0] != 0;   // block-uniform
-    if (!alone) {
-        for (int i = t; i < S * groups * 2; i += THREADS) pbuf[i] = pcdm_load_sys(part + i);
-    } else {
-        // the partners did not arrive: their chunks' partial sums, recomputed here with the same arithmetic (slow, correct, never a hang)
-        for (int ch = 0; ch < S; ++ch) {
-            if (ch == chunk) {
-                if (t < 2 * groups) pbuf[ch * groups * 2 + t] = gsum[t];
-                __syncthreads();
-                continue;
-            }
-            const int a0 = ch * rows_per_chunk, a1 = (a0 + rows_per_chunk < HW) ? a0 + rows_per_chunk : HW;
-            u16x8 w[MAXR];
-#pragma unroll
-            for (int i = 0; i < MAXR; ++i) {
-                const int r = a0 + rp + i * rows_par;
-                const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                w[i] = (active && r < a1) ? gn_src_load<SK>(src, b, (int64_t)b * HW + r, c) : z;
-            }
-            const float keep0 = t < 2 * groups ? gsum[t] : 0.f;   // (chunk_sums overwrites gsum)
-            chunk_sums(w);
-            if (t < 2 * groups) {
-                pbuf[ch * groups * 2 + t] = gsum[t];
-                gsum[t] = keep0;
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (t < groups) {
-        double ss = 0.0, qq = 0.0;
-        for (int ch = 0; ch < S; ++ch) {
-            ss += (double)pbuf[(ch * groups + t) * 2];
-            qq += (double)pbuf[(ch * groups + t) * 2 + 1];
-        }
-        const double mean = ss * inv_n;
-        double var = qq * inv_n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stat[2 * t] = (float)mean;
-        stat[2 * t + 1] = 1.0f / sqrtf((float)var + eps);
-    }
-    __syncthreads();
-    if (t == 0) {   // the partials have been read (or will never be): the last one through re-arms the counters for the next launch
-        if (pcdm_atomic_inc_agent(cnt + 1) == (unsigned)S - 1) {
-            pcdm_store_sys_u32(cnt, 0u);
-            pcdm_store_sys_u32(cnt + 1, 0u);
-        }
-    }
-    if (!active) return;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (c + e) / gs;
-        const float mean = stat[2 * g], rstd = stat[2 * g + 1];
         sc[e] = rstd * gamma[c + e];
         sh[e] = beta[c + e] - mean * sc[e];
     }
@@ -943,12 +758,6 @@ static bool gn_cluster_enabled() {
             ok = false;
         nb8 = nb8 < nb8s ? nb8 : nb8s;
         nb16 = nb16 < nb16s ? nb16 : nb16s;
-        int nbr = 0, nbrs = 0;   // the row-wise kernel (gn_rows_kernel) relies on the same co-residency, with up to 96 KiB of dynamic LDS
-        if (ok && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbr, gn_rows_kernel<512, 16, false>, 512, 96 * 1024) != hipSuccess ||
-                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbrs, gn_rows_kernel<512, 16, true>, 512, 96 * 1024) != hipSuccess))
-            ok = false;
-        nb16 = nb16 < nbr ? nb16 : nbr;
-        nb16 = nb16 < nbrs ? nb16 : nbrs;
         if (ok && ((int64_t)cus * (nb8 < nb16 ? nb8 : nb16) < kGnClusterMaxWgs || cus < kGnClusterMaxWgs)) ok = false;
         state[dev] = ok ? 1 : 2;
     }
@@ -1024,48 +833,6 @@ static int gn_launch(GnSrc src, int B, int HW, int groups, float eps, const floa
 #undef GN_FUSED
             else done = false;
             if (done) {
-                PCDM_CHECK_LAUNCH();
-                return 0;
-            }
-        }
-    }
-    {   // row-wise single pass (levels 0 / 1): wherever the cluster kernel or the two-kernel path would run and a chunk of whole rows fits
-        const int gs = C / groups, noct = C / 8;
-        static const bool rows_on = [] { const char* e = getenv("PCDM_GN_ROWS"); return !(e && e[0] == '0'); }();
-        bool coresident = true;
-#ifndef PCDM_EMU
-        coresident = gn_cluster_enabled();
-#endif
-        if (rows_on && coresident && groups <= kGnRowsMaxGroups && noct <= 512 && B <= kGnClusterMaxWgs / 2) {
-            int S = 1;
-            while (S * 2 * B <= kGnClusterMaxWgs && S * 2 <= 128) S *= 2;   // fill the chip: one workgroup per CU
-            const int rows_par = 512 / noct;
-            const int rpc = (HW + S - 1) / S;
-            const int need = (rpc + rows_par - 1) / rows_par;
-            const size_t smem = (size_t)(2 * rows_par * C + 2 * kGnRowsMaxGroups + S * groups * 2 + 2 * groups) * sizeof(float);
-            if (S >= 2 && need <= 16 && rpc >= 8 && smem <= 96 * 1024) {
-                float* part = ws + kGnClusterFloats;                                  // (the two-kernel path's area: never used by the same launch)
-                unsigned* cnt = (unsigned*)(ws + kGnClusterMaxWgs * 8);               // the cluster counters' region: [image][2]
-                unsigned* tmo = cnt + kGnClusterMaxWgs * 2;
-                const double inv_n = 1.0 / ((double)HW * gs);
-#define GN_ROWS(MR, SK_)                                                                                                                 \
-    do {                                                                                                                                 \
-        static bool attr_done = false;                                                                                                   \
-        if (!attr_done) {                                                                                                                \
-            (void)hipFuncSetAttribute((const void*)gn_rows_kernel<512, MR, SK_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-            attr_done = true;                                                                                                            \
-        }                                                                                                                                \
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_rows_kernel<512, MR, SK_>), dim3(B * S), dim3(512), smem, st, src, B, HW, groups, gs, S, rpc, eps, \
-                    inv_n, gamma, beta, fuse_silu, (u16*)y, part, cnt, tmo);                                                             \
-    } while (0)
-                if (need <= 8) {
-                    if (src.part) GN_ROWS(8, true);
-                    else GN_ROWS(8, false);
-                } else {
-                    if (src.part) GN_ROWS(16, true);
-                    else GN_ROWS(16, false);
-                }
-#undef GN_ROWS
                 PCDM_CHECK_LAUNCH();
                 return 0;
             }

@@ -314,8 +314,8 @@ def test_config0_complete_run(full):
         record_check(f"configs0.eps_part.{k}", parts[k], 2 * EPS_PART_TOL)
 
 
-FP8_TRAJ_TOL = 3e-3       # 50-step latents with fp8 attention operands against the fp32 oracle (bf16 attention: TRAJ_TOL = 1.5e-3)
-FP8_EPS_PART_TOL = 4e-2   # ... and their eps-driven part (bf16 attention: 1.2e-2; one fp8 forward: FP8_FWD_TOL = 6e-2)
+FP8_TRAJ_TOL = 1.5e-3     # 50-step latents with fp8 attention operands against the fp32 oracle: measured 0.82e-3 -- the same as with bf16
+FP8_EPS_PART_TOL = 1.2e-2  # attention (0.81e-3), so the same tolerances; eps-driven part measured 0.53e-2 (bf16: 0.52e-2)
 
 
 @pytest.mark.gpu
@@ -379,7 +379,7 @@ def test_stage3_full_size():
     m = UNet2DConditionModel(**_kwargs(cfg))
     m.load_state_dict(synth_state_dict(cfg, seed=0, random_affine=True))
     m.to(dev)
-    assert sum(int(np.prod(s)) for s in m.expected_shapes().values()) == 865_910_724
+    assert sum(int(np.prod(s)) for s in m.expected_shapes().values()) == 865_922_244
     inp = synth_stage3_inputs()
     assert abs(float(inp["latents"].double().abs().sum()) - float(fx["lat_checksum"])) <= 1e-9 * float(fx["lat_checksum"])
     sch = DDIMOracle()

@@ -39,8 +39,7 @@ def close(out, ref, tol=1e-2):
 @pytest.mark.parametrize("case", ["single", "concat_straddle", "wide", "fused16", "fused32", "fused1k", "two_pass_big", "rows", "rows_tail"])
 def test_groupnorm(backend, case):
     dev = backend.device
-    if case == "rows":       # row-wise single pass (gn_rows_kernel): chunks of whole rows, statistics exchanged between the workgroups of an
-        # image (the emulator takes its self-sufficient path: every workgroup recomputes the partners' partial sums); two-source concat
+    if case == "rows":       # long slabs that no single workgroup holds (emulator: two-kernel path; GPU: cluster kernel), two-source concat
         B, HW, C1, C2, G = (1, 4000, 64, 32, 8) if backend.is_emu else (8, 32 * 44, 640, 320, 32)
     elif case == "rows_tail":  # HW not a multiple of the chunk count, group size 10 (octets straddle groups)
         B, HW, C1, C2, G = (2, 2777, 80, 0, 8) if backend.is_emu else (8, 64 * 88 - 3, 320, 0, 32)

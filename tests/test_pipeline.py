@@ -141,10 +141,15 @@ def test_rescale_noise_cfg_kernel(backend):
 
 
 @pytest.mark.gpu
-def test_simple_pipeline_and_guidance_rescale(gpu_backend):
+def test_simple_pipeline_and_guidance_rescale(gpu_backend, monkeypatch):
     """Simple_Stage2_InpaintDiffusionPipeline (no class_labels, ref :544-887) and guidance_rescale > 0 (ref :514-516),
     fused (hipGraph) and reference-semantics modes, vs the oracle loop."""
+    import pcdms_amd.unet as U
     from pcdms_amd.pipeline import Simple_Stage2_InpaintDiffusionPipeline
+    # fused vs reference mode is a comparison of the two SCHEDULER formulations on identical UNet launches (_same_path): the
+    # CFG-shared prefix, which only the fused sampler can promise (a bare unet(...) call cannot), would put other tile configurations
+    # under the first two convolutions of one side (its own tests: test_cfg_shared_prefix_*)
+    monkeypatch.setattr(U, "SHARE_CFG_PREFIX", False)
     cfg = UNetConfig.tiny(class_embed_type=None, projection_class_embeddings_input_dim=None)
     sd = synth_state_dict(cfg, seed=2, random_affine=True)
     m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
@@ -327,11 +332,13 @@ def test_bare_unet_fresh_tensors_same_address(backend):
 
 
 @pytest.mark.gpu
-def test_two_successive_pairs_reference_mode_unipc(gpu_backend):
+def test_two_successive_pairs_reference_mode_unipc(gpu_backend, monkeypatch):
     """Two successive SINGLE-PAIR calls with different (s_img_proj_f, pred_t_img_embed, st_pose_f, masked latents) through
     one pipe in ``mode="reference"`` with UniPC (the shipped driver's scheduler, ref stage2_batchtest_inpaint_model.py:132,
     185-200), then through the fused hipGraph path with DDIM, interleaved with a reference-mode call: every result is
     compared with the oracle for ITS pair (<= 3e-2)."""
+    import pcdms_amd.unet as U
+    monkeypatch.setattr(U, "SHARE_CFG_PREFIX", False)   # (fused vs reference mode on identical UNet launches: see test_simple_pipeline_and_guidance_rescale)
     cfg = UNetConfig.tiny()
     sd, m = _build(gpu_backend, cfg, seed=1)
     dev = gpu_backend.device
@@ -405,7 +412,9 @@ def test_cfg_shared_prefix_in_the_sampler(backend, monkeypatch):
     b = _call(pipe2, inp, dev, N, steps, h, w)
     assert not pipe2._st["cond"].shared_halves
     backend.sync()
-    assert _same_path(a, b, steps_are_one=False), _rel(a, b.float().cpu())
+    # (the half-batch launches run on their own tuned tiles: other fp32 summation orders under two convolutions, amplified by the
+    #  random-weight UNet over the steps -- measured 1.4e-3 after 4 steps; the oracle comparison of either is at 3e-2)
+    assert _rel(a, b.float().cpu()) <= 5e-3, _rel(a, b.float().cpu())
     monkeypatch.setattr(U, "SHARE_CFG_PREFIX", True)
     # without CFG there are no halves
     c = _call(pipe, inp, dev, N, steps, h, w, guidance_scale=1.0)
