@@ -110,7 +110,7 @@ typedef struct pcdm_gemm_params {
     int64_t ldw;       /* row stride of W in elements (0 -> K); lets an activation slice act as the [N,K] operand */
     int32_t no_pad_lo; /* conv: 1 = zero padding at the bottom/right only (taps start AT the output pixel): the VAE
                           encoder's Downsample2D(padding=0) + F.pad(0,1,0,1); 0 = symmetric padding 1 */
-    int32_t tile;      /* 0 = heuristic; 1..26 = explicit tile configuration (gemm.hip dispatch_tile), 31..34 = the A-in-registers thin-K
+    int32_t tile;      /* 0 = heuristic; 1..26 = explicit tile configuration (gemm.hip dispatch_tile), 31..36 = the A-in-registers thin-K
                           kernel (rowgemm.hip; K = 320, linear); -1 if invalid for the problem */
     int32_t act;       /* PCDM_ACT_*: out = act(acc + bias + rowvec) + residual.  With PCDM_EPI_GEGLU: gate activation, 0 = GELU(erf) (GEGLU),
                           PCDM_ACT_SILU = SwiGLU (DINOv2 SwiGLUFFN).  SiLU: the convs of
@@ -118,7 +118,7 @@ typedef struct pcdm_gemm_params {
     int32_t zero_rows; /* linear only: the caller guarantees A rows [0, zero_rows) are all-zero; they are not read and tiles entirely
                           inside them run the epilogue only.  The CFG unconditional half of attn2.to_out: context == 0 => attention
                           output == 0 => out = bias + residual (stage2_inpaint_pipeline.py:457-458) */
-    const float* ln_wsum;  /* non-NULL (tiles 31..34 only: the A-in-registers kernel, K = 320): W and bias carry a FOLDED LayerNorm -- W' = W diag(gamma),
+    const float* ln_wsum;  /* non-NULL (tiles 31..36 only: the A-in-registers kernel, K = 320): W and bias carry a FOLDED LayerNorm -- W' = W diag(gamma),
                               bias' = bias + W beta (BasicTransformerBlock.norm1/2/3 in front of to_q|k|v, to_q and the GEGLU projection: K8 fused into
                               K7 / K11) -- and ln_wsum[n] = sum_k W'[n, k] (fp32 [Npad], of the bf16 values).  The kernel takes each A row's mean / rstd
                               (eps ln_eps) and returns rstd (acc - mean ln_wsum[n]) + bias'[n] = LayerNorm(A) W^T + bias.  Other tiles return -1 when set */

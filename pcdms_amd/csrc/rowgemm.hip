@@ -532,12 +532,18 @@ int pcdm_gemm_detail::launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st
         case 33: return launch_rg<2, 4, 3, 128, 6>(a, st);   // 96 rows, N tiles of 128 (waves 48 x 32): M = 22528 -> 235 workgroups
         case 34: return launch_rg<4, 1, 3, 64, 5, 512>(a, st);  // FOUR waves (48 x 64 each), 192 rows, N tiles of 64, two workgroups per CU
                                                                // (40 + 17 + <= 22 KiB each), N split over 512 / row-blocks workgroups
+        // Round 4, for the HBM-bound N = 320 linears with a residual (to_out / proj_out: A + residual + out = 86.5 MB against 4.6 GFLOP): tile
+        // 34 splits the five N tiles of a row block over two workgroups, i.e. reads the A rows TWICE (115 MB in all).  Smaller row blocks
+        // reach two workgroups per CU without an N split -- A, residual and out each cross the fabric once -- at the price of fewer
+        // MFMAs per W fragment read (2 / 1 instead of 3: irrelevant at 0.05 FLOP per byte).
+        case 35: return launch_rg<4, 1, 2, 64, 5>(a, st);    // four waves of 32 rows: 128-row blocks (352 workgroups at M = 45056), all N tiles
+        case 36: return launch_rg<4, 1, 1, 64, 5>(a, st);    // four waves of 16 rows: 64-row blocks (704 workgroups), all N tiles
 #ifdef PCDM_DEV_ROWGEMM_VARIANTS
-        case 35: return launch_rg<4, 2, 3, 128, 4>(a, st);   // as 31 with a 4-stage ring
-        case 36: return launch_rg<4, 2, 3, 128, 3>(a, st);   // as 31 with a 3-stage ring
-        case 37: return launch_rg<4, 1, 3, 64, 3, 512>(a, st);   // as 34 with a 3-stage ring
-        case 38: return launch_rg<4, 1, 3, 64, 4, 512>(a, st);   // as 34 with a 4-stage ring
-        case 39: return launch_rg<4, 1, 3, 64, 5, 768>(a, st);   // as 34 with the N tiles split three ways at M = 45056
+        case 40: return launch_rg<4, 2, 3, 128, 4>(a, st);   // as 31 with a 4-stage ring
+        case 41: return launch_rg<4, 2, 3, 128, 3>(a, st);   // as 31 with a 3-stage ring
+        case 42: return launch_rg<4, 1, 3, 64, 3, 512>(a, st);   // as 34 with a 3-stage ring
+        case 43: return launch_rg<4, 1, 3, 64, 4, 512>(a, st);   // as 34 with a 4-stage ring
+        case 44: return launch_rg<4, 1, 3, 64, 5, 768>(a, st);   // as 34 with the N tiles split three ways at M = 45056
 #endif
         default: return -1;
     }

@@ -237,7 +237,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
     ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  With ``pw_ln`` (the same Linear packed by ``pack_linear_ln`` /
-    ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..34, K = 320; 34 = four waves, two workgroups per CU: the one in use) needs no LayerNorm pass
+    ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..36, K = 320; 34 = four waves, two workgroups per CU: the one in use) needs no LayerNorm pass
     at all -- it takes the row statistics from the rows it holds; for every other tile the rows go through ``pcdm_layernorm`` into
     ``ln_buf`` [M, K] first (the tuner times both forms, the LayerNorm launch included, and keeps the faster).
 
@@ -404,13 +404,13 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
     return out
 
 
-ROWGEMM_TILES = (31, 32, 33, 34)   # rowgemm.hip (K = 320): id -> (BM, BN) below
+ROWGEMM_TILES = (31, 32, 33, 34, 35, 36)   # rowgemm.hip (K = 320): id -> (BM, BN) below
 # gemm.hip dispatch_tile(): id -> (BM, BN)
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),
                15: (128, 64), 16: (512, 64), 17: (256, 256), 18: (128, 128),
                21: (192, 320), 26: (192, 256),
-               31: (192, 128), 32: (192, 64), 33: (96, 128), 34: (192, 64)}
+               31: (192, 128), 32: (192, 64), 33: (96, 128), 34: (192, 64), 35: (128, 64), 36: (64, 64)}
 _TUNED: dict = {}
 _WS: dict = {}
 

@@ -689,8 +689,8 @@ def test_rowgemm_thin_k(backend):
         return F.layer_norm(x.float(), (K,), gamma, beta, 1e-5).to(BF16).float()   # the fused path rounds LN(x) to bf16, like pcdm_layernorm
 
     # ---- plain store: bias + residual, M tail, several N-tile counts
-    for (M, N, tiles) in ([(200, 128, (31, 32, 33, 34)), (100, 320, (32, 34))] if backend.is_emu else
-                          [(45056, 320, (31, 32, 33, 34)), (22528 + 40, 320, (32, 33, 34)), (45056, 960, (32, 34)), (1000, 1280, (31, 32, 33, 34))]):
+    for (M, N, tiles) in ([(200, 128, (31, 32, 33, 34, 35, 36)), (100, 320, (32, 35, 34))] if backend.is_emu else
+                          [(45056, 320, (31, 32, 33, 35, 36, 34)), (22528 + 40, 320, (32, 33, 36, 34)), (45056, 960, (32, 35, 34)), (1000, 1280, (31, 32, 33, 36, 34))]):
         a = rnd(M, K, seed=91)
         w = rnd(N, K, seed=92, scale=1 / math.sqrt(K))
         bias = torch.randn(N, generator=torch.Generator().manual_seed(93))
@@ -732,7 +732,7 @@ def test_rowgemm_thin_k(backend):
     for use_ln in (False, True):
         pr = (ln_ref(a) if use_ln else a.float()) @ w.float().t() + bias
         h, gt = pr.chunk(2, -1)
-        for tile in (31, 34):
+        for tile in (31, 35, 34):
             out = torch.full((M, D), float("nan"), dtype=BF16, device=dev)
             kw = dict(ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, K, dtype=BF16, device=dev), pw_ln=pw_ln) if use_ln else {}
             ops.gemm(a.to(dev), pw, out, epilogue=ops.EPI_GEGLU, tile=tile, **kw)
@@ -746,8 +746,8 @@ def test_rowgemm_thin_k(backend):
     pwq_ln = ops.pack_linear_ln(wq.float(), None, gamma, beta, dev)
     for use_ln in (False, True):
         pr = (ln_ref(x) if use_ln else x.float()) @ wq.float().t()
-        for tile in (31, 32, 33, 34):
-            if pwq.Npad % ops.TILE_SHAPES[tile][1] or (2 * Cc) % (ops.TILE_SHAPES[tile][1] // {31: 2, 32: 2, 33: 4, 34: 1}[tile]):
+        for tile in (31, 32, 33, 34, 36):
+            if pwq.Npad % ops.TILE_SHAPES[tile][1] or (2 * Cc) % (ops.TILE_SHAPES[tile][1] // {31: 2, 32: 2, 33: 4, 34: 1, 35: 1, 36: 1}[tile]):
                 continue
             qk = torch.full((Bq * T, 2 * Cc), float("nan"), dtype=BF16, device=dev)
             vt = torch.zeros(Bq, Cc, T + 8, dtype=BF16, device=dev)

@@ -75,8 +75,8 @@ def run(name, M, N, tile, epi, ln, extra=0):
 
 if __name__ == "__main__":
     if "--dev34" in sys.argv:   # experiments on the four-wave tile (a PCDM_DEV_ROWGEMM_VARIANTS build)
-        for tile, extra, nm in ((34, 0, "5 stages"), (34, 128, "5 stages, NO vmcnt wait (invalid results)"), (38, 0, "4 stages"), (37, 0, "3 stages"),
-                                (39, 0, "5 stages, 3-way N split"), (34, 32, "5 stages, stores dropped"), (34, 16, "5 stages, no N-tile rotation")):
+        for tile, extra, nm in ((34, 0, "5 stages"), (34, 128, "5 stages, NO vmcnt wait (invalid results)"), (43, 0, "4 stages"), (42, 0, "3 stages"),
+                                (44, 0, "5 stages, 3-way N split"), (34, 32, "5 stages, stores dropped"), (34, 16, "5 stages, no N-tile rotation")):
             run(f"ff1 {nm}", 45056, 1280, tile, ops.EPI_GEGLU, True, extra)
         raise SystemExit(0)
     run("ff1 (4 waves, 2 WGs/CU)", 45056, 1280, 34, ops.EPI_GEGLU, True)
