@@ -37,6 +37,10 @@ constexpr int KB = 64;     // keys per tile
 constexpr int QPW = 32;    // queries per wave
 constexpr int QPB = 128;   // queries per workgroup
 
+// (Round 4 measured a software-pipelined form of this kernel -- the QK^T MFMAs of tile t + 1 issued in one scheduling region with the
+//  exponentials of tile t, [1 MFMA : 4 v_exp + 2 v_cvt_pk] placed by a sched_group_barrier pipeline, K one tile ahead of V^T in the ring, 32
+//  more accumulator registers => two workgroups per CU: 786-824 TF/s at N = 5632 against this kernel's 852-892 in the same session
+//  (profiles/r4_bench_attn_pipe_ab.txt).  Three independent waves per SIMD cover each other's softmax better than a wave covers its own.)
 // ROWSUM_VALU: the softmax denominator as per-lane fp32 adds of the un-rounded P (combined across the two lane halves once, at the
 // end) instead of an MFMA against a ones fragment (4 of the 22 MFMAs per tile); which one wins depends on which pipe has slack.
 // (s_setprio 1 around the two MFMA clusters was measured too: no gain with 3 co-resident waves per SIMD -- removed.)
@@ -224,227 +228,6 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
             }
     }
 }
-// ---- software-pipelined variant (round 4).  flash_attn_kernel runs a wave's tile as QK^T MFMAs -> softmax VALU -> PV MFMAs, three strictly
-// dependent phases: the matrix pipe of a SIMD has work only while ANOTHER wave of that SIMD happens to be in an MFMA phase (SQ counters,
-// profiles/r2_pmc_attn.json: the pipe is busy ~55 % of the time at three waves per SIMD).  Here a wave overlaps with ITSELF: the scores of
-// tile t + 1 (S_next = K_{t+1} Q^T - m, ten MFMAs that depend on nothing the softmax of tile t produces) are issued in the same
-// scheduling region as the exponentials / bf16 converts of tile t, interleaved one MFMA : five VALU by sched_group_barrier, so the 32
-// v_exp of a tile sit in the shadow of ten MFMAs; the max / lazy-rescale decision of tile t comes first (it fixes the reference m that
-// S_next subtracts inside the contraction, so no correction of S_next is ever needed), the PV MFMAs of tile t last.  K therefore runs
-// one tile ahead of V^T in the LDS ring (same 32 KiB: two K stages, two V^T stages).  Costs 32 more accumulator registers (S_cur and
-// S_next): two workgroups per CU instead of three.
-template <bool ROWSUM_VALU>
-__global__ __launch_bounds__(256, 2) void flash_attn_pipe_kernel(const u16* __restrict__ q, int64_t ldq,
-                                                              const u16* __restrict__ k, int64_t ldk,
-                                                              const u16* __restrict__ vt, int64_t ldvt,
-                                                              u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
-                                                              float c /* scale * log2(e) */, float thr) {
-    __shared__ __attribute__((aligned(16))) u16 KV[2][2][KB * 64];   // [stage][K | V^T][row * 64 + col]
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QPB + wave * QPW;
-    const int hh = lane >> 5, col = lane & 31;
-    int qrow = q0 + col;
-    const bool qvalid = qrow < Lq;
-    if (!qvalid) qrow = Lq - 1;
-    const u16* qp = q + ((int64_t)b * Lq + qrow) * ldq + h * 64 + hh * 8;
-    u16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const u16x8 raw = *(const u16x8*)(qp + ks * 16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[ks][e] = f2bf(bf2f(raw[e]) * c);
-    }
-    constexpr uint32_t kOOB = 0x80000000u;
-    const int srow = lane >> 3, spos = lane & 7;
-    const BufRsrc rs_k = make_buf_rsrc(k + (int64_t)b * Lk * ldk + h * 64);
-    const BufRsrc rs_v = make_buf_rsrc(vt + ((int64_t)(b * H + h) * 64) * ldvt);
-    uint32_t k_off[2], v_off[2];
-    int v_chunk[2], k_row[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rl = (wave * 2 + j) * 8 + srow;
-        const int gch = spos ^ ((rl >> 1) & 7);
-        k_row[j] = rl;
-        k_off[j] = (uint32_t)((int64_t)rl * ldk * 2) + gch * 16u;
-        v_off[j] = (uint32_t)((int64_t)rl * ldvt * 2) + gch * 16u;
-        v_chunk[j] = gch * 8;
-    }
-    auto issue_k = [&](int key0, int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            buf_glds16(rs_k, key0 + k_row[j] < Lk ? k_off[j] : kOOB, (uint32_t)((int64_t)key0 * ldk * 2), &KV[buf][0][(wave * 2 + j) * 8 * 64]);
-    };
-    auto issue_v = [&](int key0, int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            buf_glds16(rs_v, key0 + v_chunk[j] < ldvt ? v_off[j] : kOOB, (uint32_t)(key0 * 2), &KV[buf][1][(wave * 2 + j) * 8 * 64]);
-    };
-    f32x16 oacc[2], lacc, s_cur[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = lacc[r] = s_cur[0][r] = s_cur[1][r] = 0.f;
-    float m_ref = 0.f;
-    u16x8 qm = {0, 0, 0, 0, 0, 0, 0, 0};
-    const u16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-    const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);
-    const int sw_k = (pi >> 1) & 7, sw_v = (col >> 1) & 7;
-    const int nkb = (Lk + KB - 1) / KB;
-
-    // ---- prologue: K_0, V^T_0, K_1 in flight; S_cur = K_0 Q^T (no reference yet: the first tile always sets it)
-    issue_k(0, 0);
-    issue_v(0, 0);
-    if (nkb > 1) issue_k(KB, 1);
-    glds_wait();
-    __syncthreads();
-    {
-        u16x8 kfr[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf) kfr[ks][kf] = *(const u16x8*)&KV[0][0][(kf * 32 + pi) * 64 + (((ks * 2 + hh) ^ sw_k) * 8)];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf) s_cur[kf] = mfma_32x32x16(kfr[ks][kf], qf[ks], s_cur[kf]);
-    }
-    // iteration kb: softmax + PV of tile kb (scores in s_cur), scores of tile kb + 1.  K tile i lives in K stage i & 1, V^T tile i in V stage i & 1.
-    auto tile_step = [&](int kb, auto cur_tag) {
-        constexpr int cur = decltype(cur_tag)::value;     // = kb & 1
-        const int key0 = kb * KB;
-        const bool more = kb + 1 < nkb;
-        if (kb > 0) {          // (the prologue has already waited for K_0 / V_0 / K_1)
-            glds_wait();       // this wave's parts of V^T_kb and K_{kb+1} have landed ...
-            __syncthreads();   // ... everybody's have; and everybody is done with K_kb (stage cur) and V^T_{kb-1} (stage cur ^ 1)
-        }
-        if (kb + 2 < nkb) issue_k(key0 + 2 * KB, cur);
-        if (more) issue_v(key0 + KB, cur ^ 1);
-        // (behind the last tile there is no K_{kb+1}: the reads, and the MFMAs below, then run on stale LDS bytes and their result is never
-        //  used -- unconditional, because a branch around them would end the scheduling region the interleaving needs)
-        u16x8 kfr[4][2], vfr[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-                kfr[ks][kf] = *(const u16x8*)&KV[cur ^ 1][0][(kf * 32 + pi) * 64 + (((ks * 2 + hh) ^ sw_k) * 8)];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int df = 0; df < 2; ++df) vfr[s4][df] = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
-        // ---- tile kb: tail mask, maximum, lazy reference update
-        if (key0 + KB > Lk) {
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key0 + 32 * kf + 16 * (r >> 3) + 8 * hh + (r & 7) >= Lk) s_cur[kf][r] = -1e30f;
-        }
-        float mx = s_cur[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const bool bump = kb == 0 || mx > thr;
-        if (wave_any(bump)) {
-            const float m_new = bump ? bf2f(f2bf(m_ref + mx)) : m_ref;
-            const float delta = m_new - m_ref;
-            const float alpha = fast_exp2(-delta);
-            m_ref = m_new;
-            qm[0] = hh == 0 ? f2bf(-m_new) : (u16)0;
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s_cur[kf][r] -= delta;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                oacc[0][r] *= alpha;
-                oacc[1][r] *= alpha;
-            }
-            lacc[0] *= alpha;
-        }
-        // ---- S_next = K_{kb+1} Q^T - m (10 MFMAs) with P = exp2(S_cur) -> bf16 (32 v_exp + 16 v_cvt_pk) placed in the MFMA gaps by hand:
-        // MFMA i, then two (later one) "units" of two exponentials + one packed convert -- written in that order and pinned by a
-        // sched_group_barrier pipeline (left to itself hipcc issues the ten MFMAs back to back and the whole VALU block behind them; plain
-        // sched_barrier fences do not help: the exponentials are pure and get moved at IR level before the machine scheduler sees them)
-        f32x16 s_next[2];
-        u32x4 pw[4];
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        auto unit = [&](int u) {   // scores 2 (u & 7), 2 (u & 7) + 1 of fragment u >> 3
-            const int kf = u >> 3, r = (u & 7) * 2;
-            const float p0 = fast_exp2(s_cur[kf][r]), p1 = fast_exp2(s_cur[kf][r + 1]);
-            if constexpr (ROWSUM_VALU) {
-                part[u & 3] += p0;
-                part[(u + 2) & 3] += p1;
-            }
-            pw[2 * kf + (r >> 3)][(r & 7) >> 1] = pack2bf(p0, p1);
-        };
-        PCDM_SCHED_BARRIER();
-        {
-            int u = 0;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                if (i < 8) {
-                    const int ks = i >> 1, kf = i & 1;
-                    s_next[kf] = mfma_32x32x16(kfr[ks][kf], qf[ks], i < 2 ? zero16 : s_next[kf]);
-                } else {
-                    s_next[i - 8] = mfma_32x32x16(ones, qm, s_next[i - 8]);
-                }
-                const int nu = i < 6 ? 2 : 1;
-#pragma unroll
-                for (int j = 0; j < nu; ++j) unit(u + j);
-                u += nu;
-            }
-        }
-#ifndef PCDM_EMU
-        // the placement, as a scheduling pipeline: [1 MFMA, 6 VALU] x 6, [1 MFMA, 3 VALU] x 4 (a unit = 2 v_exp + 1 v_cvt_pk)
-#define PCDM_SGB(NT, NV)                                  \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x400, NT, 0);   \
-    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-        // (mask 0x400 = transcendental: v_exp_f32 is not a member of the 0x002 VALU group)
-        if constexpr (ROWSUM_VALU) {
-            PCDM_SGB(4, 6) PCDM_SGB(4, 6) PCDM_SGB(4, 6) PCDM_SGB(4, 6) PCDM_SGB(4, 6) PCDM_SGB(4, 6) PCDM_SGB(2, 3) PCDM_SGB(2, 3) PCDM_SGB(2, 3) PCDM_SGB(2, 3)
-        } else {
-            PCDM_SGB(4, 2) PCDM_SGB(4, 2) PCDM_SGB(4, 2) PCDM_SGB(4, 2) PCDM_SGB(4, 2) PCDM_SGB(4, 2) PCDM_SGB(2, 1) PCDM_SGB(2, 1) PCDM_SGB(2, 1) PCDM_SGB(2, 1)
-        }
-#undef PCDM_SGB
-#endif
-        if constexpr (ROWSUM_VALU) lacc[0] += (part[0] + part[1]) + (part[2] + part[3]);
-        u16x8 pf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pf[i] = __builtin_bit_cast(u16x8, pw[i]);
-        // ---- O^T += V^T P^T (+ row sums on the matrix pipe)
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-            for (int df = 0; df < 2; ++df) oacc[df] = mfma_32x32x16(vfr[s4][df], pf[s4], oacc[df]);
-            if constexpr (!ROWSUM_VALU) lacc = mfma_32x32x16(ones, pf[s4], lacc);
-        }
-        s_cur[0] = s_next[0];
-        s_cur[1] = s_next[1];
-    };
-    for (int kb = 0; kb < nkb; kb += 2) {
-        tile_step(kb, std::integral_constant<int, 0>{});
-        if (kb + 1 < nkb) tile_step(kb + 1, std::integral_constant<int, 1>{});
-    }
-    const float l_tot = ROWSUM_VALU ? lacc[0] + __shfl_xor(lacc[0], 32, 64) : lacc[0];
-    const float inv = 1.0f / l_tot;
-    if (qvalid) {
-        u16* op = o + ((int64_t)b * Lq + qrow) * ldo + h * 64;
-#pragma unroll
-        for (int df = 0; df < 2; ++df)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                u16x4 ov;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = f2bf(oacc[df][4 * rg + e] * inv);
-                *(u16x4*)(op + df * 32 + 8 * rg + 4 * hh) = ov;
-            }
-    }
-}
-
 // ---- N4: the same attention with e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), twice the
 // bf16 MFMA rate: K and V^T arrive quantised (pcdm_quantize_fp8: once per projection, every query block re-reads them), Q is scaled and
 // converted once per workgroup, P is converted as it leaves the exp.  Per 64-key tile a wave issues 2 (QK^T, one per 32 keys: K = 64
@@ -652,9 +435,6 @@ extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, i
 
 // A/B switch of the row-sum path (tools/bench_attn.py; PCDM_ATTN_ROWSUM=valu|mfma in the environment at load time)
 static bool g_rowsum_valu = [] { const char* e = getenv("PCDM_ATTN_ROWSUM"); return e && e[0] == 'v'; }();
-// software-pipelined kernel: -1 = by key count (default), 0 = never, 1 = always; PCDM_ATTN_PIPE_MIN_LK: the key count from which it is used
-static int g_attn_pipe = [] { const char* e = getenv("PCDM_ATTN_PIPE"); return e ? atoi(e) : -1; }();
-static int g_attn_pipe_min_lk = [] { const char* e = getenv("PCDM_ATTN_PIPE_MIN_LK"); return e ? atoi(e) : 1024; }();
 // extra dynamic LDS per workgroup: an occupancy knob for experiments (e.g. 50000 -> 2 workgroups per CU instead of 3)
 static int g_lds_pad = [] { const char* e = getenv("PCDM_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
 
@@ -665,19 +445,11 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
-#define PCDM_ATTN_LAUNCH(KERNEL, RS)                                                                                                    \
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(KERNEL<RS>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk,         \
+#define PCDM_ATTN_LAUNCH(RS)                                                                                                            \
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
                 (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2)
-    // the software-pipelined kernel pays off where a wave has many key tiles to pipeline over (self-attention); the short cross-attention
-    // loops (L = 258: five tiles) keep the three-workgroups-per-CU kernel.  PCDM_ATTN_PIPE = 0 / 1 forces one of them (A/B runs)
-    const bool pipe = g_attn_pipe < 0 ? Lk >= g_attn_pipe_min_lk : g_attn_pipe > 0;
-    if (pipe) {
-        if (g_rowsum_valu) PCDM_ATTN_LAUNCH(flash_attn_pipe_kernel, true);
-        else PCDM_ATTN_LAUNCH(flash_attn_pipe_kernel, false);
-    } else {
-        if (g_rowsum_valu) PCDM_ATTN_LAUNCH(flash_attn_kernel, true);
-        else PCDM_ATTN_LAUNCH(flash_attn_kernel, false);
-    }
+    if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true);
+    else PCDM_ATTN_LAUNCH(false);
 #undef PCDM_ATTN_LAUNCH
     PCDM_CHECK_LAUNCH();
     return 0;

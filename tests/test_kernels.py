@@ -916,16 +916,3 @@ def test_conv_dup_rows_shared_cfg_prefix(backend):
     pwl = ops.pack_linear(rnd(64, 64, seed=1).float(), None, dev)
     with pytest.raises((RuntimeError, AssertionError)):
         ops.gemm(rnd(64, 64, seed=2).to(dev), pwl, torch.empty(128, 64, dtype=BF16, device=dev), dup_rows=64, tile=2)
-
-
-def test_flash_attn_pipelined_kernel_under_the_emulator():
-    """``flash_attn_pipe_kernel`` (the software-pipelined self-attention kernel, chosen for Lk >= 1024) on the emulator's small shapes: the
-    kernel choice is read from the environment when the library is loaded, so the four ``test_flash_attn[emu-*]`` cases (tail masking, the
-    258-token context, the 88-token level, the late-spike case) are re-run in a child process with ``PCDM_ATTN_PIPE=1``."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, PCDM_ATTN_PIPE="1", PCDM_TEST_SERIAL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-p", "no:xdist", "-p", "no:cacheprovider", "-m", "not gpu",
-                        "-k", "test_flash_attn and emu and not fp8 and not pipelined"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
