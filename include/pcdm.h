@@ -242,7 +242,10 @@ int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s);
  *   "time_embedding.linear_1/2", "class_embedding.linear_1/2" (bf16 [N, K] unpadded + fp32 bias, for pcdm_small_linear)
  * Vectors (fp32): N"norm1.weight" / ".bias", N"norm2.*" (resnets), N"norm.*" and N"transformer_blocks.0.norm{1,2,3}.*" (transformers),
  *   "conv_norm_out.weight" / ".bias".
- * Tile hints (optional, pcdm_unet_set_tile): the (tile, split_k) pcdm_gemm should use for a problem key; without one the library heuristic.
+ * Tile choices: a new context starts with the committed tuning table (pcdms_amd/tuning/gfx950.json, measured on MI355X; compiled in through
+ * csrc/tuning_table.inc) -- the (tile, split_k) pcdm_gemm should use for a problem key (ln, M, Npad, K, conv, stride, upsample, epilogue,
+ * two_source, residual, flag: 1 = zero_rows, 2 = dup_rows); pcdm_unet_set_tile overrides / adds entries, pcdm_unet_get_tile reads one (-1: none:
+ * the library heuristic decides).
  * Return codes as everywhere; pcdm_unet_last_error names the missing weight / failing call. */
 typedef struct pcdm_unet pcdm_unet;
 typedef struct pcdm_unet_config {
@@ -266,6 +269,8 @@ int pcdm_unet_set_weight(pcdm_unet* u, const char* name, const void* w_bf16, con
 int pcdm_unet_set_vector(pcdm_unet* u, const char* name, const float* v, int n);
 int pcdm_unet_set_tile(pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source, int residual,
                        int zero_rows, int tile, int split_k);
+int pcdm_unet_get_tile(const pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source, int residual,
+                       int flag, int* tile, int* split_k);
 int64_t pcdm_unet_workspace_bytes(pcdm_unet* u, int B, int h, int w, int L);
 int pcdm_unet_workspace_init(pcdm_unet* u, int B, int h, int w, int L, void* workspace, pcdm_stream_t s);
 /* ehs fp32 [B, L, cross_attention_dim]; class_labels fp32 [B, K of class_embedding.linear_1] or NULL; pose fp32 NCHW [pose_b = 1 | B, C0, h, w] or

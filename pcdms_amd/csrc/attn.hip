@@ -40,15 +40,14 @@ constexpr int QPB = 128;   // queries per workgroup
 // (Round 4 measured a software-pipelined form of this kernel -- the QK^T MFMAs of tile t + 1 issued in one scheduling region with the
 //  exponentials of tile t, [1 MFMA : 4 v_exp + 2 v_cvt_pk] placed by a sched_group_barrier pipeline, K one tile ahead of V^T in the ring, 32
 //  more accumulator registers => two workgroups per CU: 786-824 TF/s at N = 5632 against this kernel's 852-892 in the same session
-//  (profiles/r4_bench_attn_pipe_ab.txt).  Three independent waves per SIMD cover each other's softmax better than a wave covers its own.)
+//  (profiles/r4_bench_attn_pipe_ab.txt).  Three independent waves per SIMD cover each other's softmax better than a wave covers its own.
+//  A FOUR-workgroups-per-CU instance of this kernel (fragments read in halves, V^T requested behind the exponentials, 128 VGPRs) spilled
+//  80-112 B per lane and ran at 630 TF/s (profiles/r4_bench_attn_lowreg_ab.txt): the 166 registers of this form are its working set.)
 // ROWSUM_VALU: the softmax denominator as per-lane fp32 adds of the un-rounded P (combined across the two lane halves once, at the
 // end) instead of an MFMA against a ones fragment (4 of the 22 MFMAs per tile); which one wins depends on which pipe has slack.
 // (s_setprio 1 around the two MFMA clusters was measured too: no gain with 3 co-resident waves per SIMD -- removed.)
-// LOWREG (round 4): a register diet for FOUR workgroups per CU (<= 128 VGPRs; 4 x 32 KiB of LDS) instead of three -- the K fragments are
-// read and multiplied in two halves, the V^T fragments are requested only behind the exponentials (their LDS latency is then exposed to
-// the wave, and covered by the three other waves of its SIMD).
-template <bool ROWSUM_VALU, bool LOWREG = false>
-__global__ __launch_bounds__(256, LOWREG ? 4 : 3) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
+template <bool ROWSUM_VALU>
+__global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
                                                          const u16* __restrict__ k, int64_t ldk,
                                                          const u16* __restrict__ vt, int64_t ldvt,
                                                          u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
@@ -128,33 +127,26 @@ __global__ __launch_bounds__(256, LOWREG ? 4 : 3) void flash_attn_kernel(const u
         for (int r = 0; r < 16; ++r) s[0][r] = s[1][r] = 0.f;
         // all 8 K fragments first (8 ds_read_b128 in flight), then the 8 MFMAs: left alone, hipcc pairs every MFMA with its own
         // ds_read + s_waitcnt and exposes one LDS latency per MFMA
-        constexpr int KH = LOWREG ? 2 : 1;                 // K / V^T fragments in KH batches of 8 / KH
-        u16x8 vfr[4][2];
+        u16x8 kfr[4][2];
 #pragma unroll
-        for (int half = 0; half < KH; ++half) {
-            u16x8 kfr[4 / KH][2];
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4 / KH; ++ks)
+            for (int kf = 0; kf < 2; ++kf)
+                kfr[ks][kf] = *(const u16x8*)&KV[cur][0][(kf * 32 + pi) * 64 + (((ks * 2 + hh) ^ sw_k) * 8)];
+        PCDM_SCHED_BARRIER();
 #pragma unroll
-                for (int kf = 0; kf < 2; ++kf)
-                    kfr[ks][kf] = *(const u16x8*)&KV[cur][0][(kf * 32 + pi) * 64 + ((((half * (4 / KH) + ks) * 2 + hh) ^ sw_k) * 8)];
-            PCDM_SCHED_BARRIER();
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4 / KH; ++ks)
-#pragma unroll
-                for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(kfr[ks][kf], qf[half * (4 / KH) + ks], s[kf]);
-            if (KH > 1) PCDM_SCHED_BARRIER();
-        }
+            for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(kfr[ks][kf], qf[ks], s[kf]);
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf) s[kf] = mfma_32x32x16(ones, qm, s[kf]);   // S' = S - m_ref
-        if constexpr (!LOWREG) {
-            // the V^T fragments of this tile are requested now, so that their LDS latency hides behind the softmax VALU work
+        // the V^T fragments of this tile are requested now, so that their LDS latency hides behind the softmax VALU work
+        u16x8 vfr[4][2];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int df = 0; df < 2; ++df)
-                    vfr[s4][df] = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
-        }
+            for (int df = 0; df < 2; ++df)
+                vfr[s4][df] = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + (((s4 * 2 + hh) ^ sw_v) * 8)];
         PCDM_SCHED_BARRIER();
         // lane holds: s[kf][r] = score(query col, key key0 + 32kf + 16(r>>3) + 8hh + (r&7))
         if (key0 + KB > Lk) {
@@ -209,30 +201,11 @@ __global__ __launch_bounds__(256, LOWREG ? 4 : 3) void flash_attn_kernel(const u
         }
         // ---- O^T += V^T P^T ; row sums += 1^T P^T (the softmax denominator is accumulated by the matrix pipe,
         //      which has slack here, instead of 32 VALU adds per tile -- the kernel is VALU-bound at d = 64)
-        if constexpr (LOWREG) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                PCDM_SCHED_BARRIER();
+        for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-                for (int s4 = 0; s4 < 2; ++s4)
-#pragma unroll
-                    for (int df = 0; df < 2; ++df)
-                        vfr[s4][df] = *(const u16x8*)&KV[cur][1][(df * 32 + col) * 64 + ((((half * 2 + s4) * 2 + hh) ^ sw_v) * 8)];
-                PCDM_SCHED_BARRIER();
-#pragma unroll
-                for (int s4 = 0; s4 < 2; ++s4) {
-#pragma unroll
-                    for (int df = 0; df < 2; ++df) oacc[df] = mfma_32x32x16(vfr[s4][df], pf[half * 2 + s4], oacc[df]);
-                    if constexpr (!ROWSUM_VALU) lacc = mfma_32x32x16(ones, pf[half * 2 + s4], lacc);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-                for (int df = 0; df < 2; ++df) oacc[df] = mfma_32x32x16(vfr[s4][df], pf[s4], oacc[df]);
-                if constexpr (!ROWSUM_VALU) lacc = mfma_32x32x16(ones, pf[s4], lacc);
-            }
+            for (int df = 0; df < 2; ++df) oacc[df] = mfma_32x32x16(vfr[s4][df], pf[s4], oacc[df]);
+            if constexpr (!ROWSUM_VALU) lacc = mfma_32x32x16(ones, pf[s4], lacc);
         }
     };
 
@@ -464,7 +437,6 @@ extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, i
 
 // A/B switch of the row-sum path (tools/bench_attn.py; PCDM_ATTN_ROWSUM=valu|mfma in the environment at load time)
 static bool g_rowsum_valu = [] { const char* e = getenv("PCDM_ATTN_ROWSUM"); return e && e[0] == 'v'; }();
-static bool g_attn_lowreg = [] { const char* e = getenv("PCDM_ATTN_LOWREG"); return e && e[0] == '1'; }();
 // extra dynamic LDS per workgroup: an occupancy knob for experiments (e.g. 50000 -> 2 workgroups per CU instead of 3)
 static int g_lds_pad = [] { const char* e = getenv("PCDM_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
 
@@ -475,16 +447,11 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
-#define PCDM_ATTN_LAUNCH(RS, LR)                                                                                                        \
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS, LR>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
+#define PCDM_ATTN_LAUNCH(RS)                                                                                                            \
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
                 (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2)
-    if (g_attn_lowreg) {   // (PCDM_ATTN_LOWREG=1: the four-workgroups-per-CU instance, A/B runs)
-        if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true, true);
-        else PCDM_ATTN_LAUNCH(false, true);
-    } else {
-        if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true, false);
-        else PCDM_ATTN_LAUNCH(false, false);
-    }
+    if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true);
+    else PCDM_ATTN_LAUNCH(false);
 #undef PCDM_ATTN_LAUNCH
     PCDM_CHECK_LAUNCH();
     return 0;

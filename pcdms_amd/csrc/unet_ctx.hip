@@ -376,6 +376,12 @@ extern "C" pcdm_unet* pcdm_unet_create(const pcdm_unet_config* cfg) {
         if (cfg->block_out_channels[i] % 64 || cfg->heads[i] <= 0 || cfg->block_out_channels[i] / cfg->heads[i] != 64) return nullptr;
     pcdm_unet* u = new pcdm_unet();
     u->cfg = *cfg;
+    // the committed tuning table (pcdms_amd/tuning/gfx950.json, measured on MI355X by tools/tune_gemm_shapes.py) is compiled in: a host
+    // without the Python tuner runs on the measured (tile, split-K) set from the start; pcdm_unet_set_tile overrides single entries
+    static const int kTable[][13] = {
+#include "tuning_table.inc"
+    };
+    for (const auto& r : kTable) u->tiles[TileKey{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]}] = {r[11], r[12]};
     return u;
 }
 
@@ -404,6 +410,16 @@ extern "C" int pcdm_unet_set_tile(pcdm_unet* u, int ln, int M, int Npad, int K, 
                                   int residual, int zero_rows, int tile, int split_k) {
     if (!u || tile < 0) return -1;
     u->tiles[TileKey{ln, M, Npad, K, conv, stride, upsample, epilogue, two_source, residual, zero_rows}] = {tile, split_k};
+    return 0;
+}
+
+extern "C" int pcdm_unet_get_tile(const pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source,
+                                  int residual, int flag, int* tile, int* split_k) {
+    if (!u) return -1;
+    auto it = u->tiles.find(TileKey{ln, M, Npad, K, conv, stride, upsample, epilogue, two_source, residual, flag});
+    if (it == u->tiles.end()) return -1;
+    if (tile) *tile = it->second.first;
+    if (split_k) *split_k = it->second.second;
     return 0;
 }
 

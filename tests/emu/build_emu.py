@@ -28,9 +28,11 @@ def _cxx() -> str:
 def build(force: bool = False) -> Path:
     OUT.mkdir(exist_ok=True)
     deps = [CSRC / s for s in SOURCES] + [CSRC / "pcdm_device.h", CSRC / "gemm_args.h", ROOT / "include" / "pcdm.h", HERE / "hip_emu.h",
-                                          HERE / "hip_emu.cpp"]
+                                          HERE / "hip_emu.cpp", ROOT / "pcdms_amd" / "tuning" / "gfx950.json"]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB
+    from pcdms_amd.build import write_tuning_include
+    write_tuning_include()        # (csrc/tuning_table.inc: included by unet_ctx.hip)
     cxx = _cxx()
     objs = []
     common = ["-O2", "-std=c++17", "-fPIC", "-DPCDM_EMU", "-Wno-unknown-attributes", "-Wno-unused-value"]

@@ -266,3 +266,44 @@ def test_cfg_shared_prefix_is_exact(backend, monkeypatch):
     out_py, out_c = run(True)
     assert torch.equal(ref_py, ref_c) and torch.equal(out_py, out_c)
     assert torch.equal(out_py, ref_py), (out_py - ref_py).abs().max()
+
+
+def test_c_context_starts_with_the_committed_tuning_table():
+    """``pcdm_unet_create`` compiles the committed tuning table in (csrc/tuning_table.inc, generated from pcdms_amd/tuning/gfx950.json): a host
+    without the Python tuner runs on the measured tile set.  The committed include must be what the JSON generates, and
+    a fresh context must answer with the table's entries -- tiled, LayerNorm-folded, zero_rows and split-K ones."""
+    import ctypes as C
+    import json
+
+    from pcdms_amd import _lib
+    from pcdms_amd.build import CSRC, ROOT, write_tuning_include
+    before = (CSRC / "tuning_table.inc").read_text()
+    assert write_tuning_include().read_text() == before, "csrc/tuning_table.inc is stale: run python -m pcdms_amd.build and commit it"
+    try:
+        lib = _lib.lib()
+    except RuntimeError:
+        from tests.emu import build_emu
+        _lib.use_library(build_emu.load())
+        lib = _lib.lib()
+    cfg = _lib.UNetConfig()
+    cfg.out_channels, cfg.n_levels, cfg.layers_per_block, cfg.cross_attention_dim, cfg.norm_groups, cfg.norm_eps = 4, 1, 1, 64, 32, 1e-5
+    cfg.block_out_channels[0], cfg.heads[0], cfg.cross_attn[0] = 64, 1, 1
+    h = lib.pcdm_unet_create(C.byref(cfg))
+    assert h
+    tab = json.loads((ROOT / "tuning" / "gfx950.json").read_text())["gemm"]
+    seen = {"ln": 0, "zero_rows": 0, "split": 0, "plain": 0}
+    for k, (tile, split) in tab.items():
+        f = k.split(",")
+        if f[0] == "ln":
+            args, kind = (1, int(f[1]), int(f[2]), int(f[3]), 0, 0, 0, int(f[4]), 0, 0, 0), "ln"
+        else:
+            flag = 0 if len(f) < 10 else (1 if f[9] == "True" else int(f[9]))
+            args = (0, int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7] == "True"), int(f[8] == "True"), flag)
+            kind = "zero_rows" if flag == 1 else ("split" if split > 1 else "plain")
+        t, sp = C.c_int(-1), C.c_int(-1)
+        assert lib.pcdm_unet_get_tile(h, *args, C.byref(t), C.byref(sp)) == 0, k
+        assert (t.value, sp.value) == (tile, split), (k, t.value, sp.value)
+        seen[kind] += 1
+    assert all(v > 0 for v in seen.values()), seen
+    assert lib.pcdm_unet_get_tile(h, 0, 12345, 64, 64, 0, 0, 0, 0, 0, 0, 0, None, None) == -1
+    lib.pcdm_unet_destroy(h)
