@@ -54,6 +54,8 @@ typedef struct pcdm_gn_splitk_src {
     const float* bias;     /* [Npad] or NULL */
     const float* rowvec;   /* fp32 [B, ldrv] or NULL (rows_per_batch of the producing call must be HW) */
     int64_t ldrv;
+    const int32_t* rowvec_step;   /* as pcdm_gemm_params.rowvec_step / rowvec_step_stride */
+    int64_t rowvec_step_stride;
     const void* residual;  /* bf16 [M, ldr] or NULL (res_mod = M) */
     int64_t ldr;
     void* pre_out;
@@ -128,6 +130,10 @@ typedef struct pcdm_gemm_params {
                               pcdm_groupnorm_splitk (the GroupNorm that follows every split-K convolution of the UNet: conv1 -> norm2, conv2 ->
                               the next block's norm) reads the slabs, so the reduce launch, its bf16 write and the norm's read of it disappear.
                               ws must stay untouched until that consumer has run (same stream). */
+    const int32_t* rowvec_step;  /* optional DEVICE counter: the row vector block in use is rowvec + (*rowvec_step) * rowvec_step_stride floats -- the
+                                    time-embedding projections of EVERY denoise step are computed once per sampling call (they depend on the
+                                    timestep table and the class labels only) and a captured step picks its block by the device step index */
+    int64_t rowvec_step_stride;
     int32_t dup_rows;      /* conv3x3 + PCDM_EPI_STORE only, > 0: the M rows computed are ALSO written as rows m + dup_rows of out (which then has
                               M + dup_rows rows), with the row-vector row (m + dup_rows) / rows_per_batch and the residual row m + dup_rows of
                               their own: one contraction, two epilogues.  For a batch whose second half has the same conv INPUT as the first
@@ -135,7 +141,7 @@ typedef struct pcdm_gemm_params {
                               conv1 (stage2_inpaint_pipeline.py:499-501 doubles the latents; mask, masked latents and pose are shared).  Needs
                               N % 8 == 0, ldo % 8 == 0, rows_per_batch >= 32 and dup_rows % rows_per_batch == 0 with a rowvec; else -1 */
 } pcdm_gemm_params;
-/* pcdm_version() == 2: the struct above ends with defer_reduce, dup_rows (1: ended with ln_eps).  Zero-initialise it (memset) and build against
+/* pcdm_version() == 2: the struct above ends with defer_reduce, rowvec_step, rowvec_step_stride, dup_rows (1: ended with ln_eps).  Zero-initialise it (memset) and build against
  * the header of the library in use: a host compiled against an older header passes a shorter struct. */
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 
@@ -173,6 +179,13 @@ int pcdm_timestep_embedding(const int64_t* t_dev, const int32_t* step_dev, float
                             int flip_sin_to_cos, float shift, pcdm_stream_t s);
 int pcdm_small_linear(const float* x, const void* w, const float* bias, const float* add, float* y, int B, int K,
                       int N, int act_in, int act_out, pcdm_stream_t s);
+/* The same embeddings for a whole timestep TABLE (once per sampling call instead of five launches per denoise step):
+ * pcdm_timestep_embedding_rows: out[i, :] = Timesteps(t_dev[i]), i < n (fp32 [n, dim]);
+ * pcdm_time_class_combine: out[i * B + b, :] = bf16( silu( emb_t[i, :] + (cls ? cls[b, :] : 0) ) ) -- emb = time_embedding(t_i) + class_embedding(b)
+ *   as every ResnetBlock2D consumes it (silu(emb)), for all steps and batch entries: the A operand of ONE time_emb_proj GEMM with
+ *   M = n * B rows.  Same per-row arithmetic as the per-step launches (bit-identical results). */
+int pcdm_timestep_embedding_rows(const int64_t* t_dev, int n, float* out, int dim, int flip_sin_to_cos, float shift, pcdm_stream_t s);
+int pcdm_time_class_combine(const float* emb_t, const float* cls, void* out_bf16, int n, int B, int D, pcdm_stream_t s);
 
 /* ---- P-2 input assembly: cat([cat([latents]*2), mask, masked_latents], 1) (stage2_inpaint_pipeline.py:499-501)
  * -> NHWC bf16 [Bout, h, w, cpad] with channels >= 9 zero.  latents fp32 NCHW [N,4,h,w]; Bout = rep*N rows
@@ -281,6 +294,13 @@ int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w, int L, con
  * same x_in rows and pose feature (the two classifier-free-guidance halves: stage2_inpaint_pipeline.py:499-501 doubles the latents and shares
  * mask / masked latents / pose): conv_in, the first norm1 and the first conv1's contraction then run once for both halves. */
 int pcdm_unet_set_shared_cfg_input(pcdm_unet* u, void* workspace, int shared);
+/* Optional, after pcdm_unet_prepare_conditioning on the same workspace: the time / class embedding MLPs (ref :661-708) and every
+ * ResnetBlock2D.time_emb_proj for ALL n timesteps of t_dev, once per sampling call (2 + 2 ceil(n / 32) + 2 launches) instead of five launches
+ * per denoise step.  table: caller-owned device memory of pcdm_unet_time_table_bytes(u, n, B) bytes, alive while forwards use it.
+ * pcdm_unet_forward calls on this workspace that pass the same t_dev and a device step counter pick their block by that counter; any other
+ * call computes the embeddings per step as before.  Bit-identical to the per-step launches. */
+int64_t pcdm_unet_time_table_bytes(const pcdm_unet* u, int n, int B);
+int pcdm_unet_prepare_timesteps(pcdm_unet* u, const int64_t* t_dev, int n, void* table, void* workspace, pcdm_stream_t s);
 /* x_in NHWC bf16 [B, h, w, conv_in.cin] (pcdm_assemble_input / pcdm_nchw_f32_to_nhwc_bf16); timestep = t_dev[step_dev ? *step_dev : 0] (device);
  * pose_b as passed to prepare_conditioning (0: no pose); eps_out fp32 NCHW [B, out_channels, h, w] */
 int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* t_dev, const int32_t* step_dev, int B, int h, int w, int L, int pose_b,

@@ -40,7 +40,8 @@ class GemmParams(C.Structure):
         ("split_k", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("ldw", C.c_int64), ("no_pad_lo", C.c_int32), ("tile", C.c_int32), ("act", C.c_int32),
         ("zero_rows", C.c_int32),
-        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32), ("dup_rows", C.c_int32),
+        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
+        ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64), ("dup_rows", C.c_int32),
     ]
 
 
@@ -48,8 +49,8 @@ class GnSplitKSrc(C.Structure):
     """Mirror of ``pcdm_gn_splitk_src`` (include/pcdm.h)."""
 
     _fields_ = [("part", C.c_void_p), ("split_k", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32),
-                ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ldrv", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
-                ("pre_out", C.c_void_p), ("store_pre", C.c_int32)]
+                ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ldrv", C.c_int64), ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64),
+                ("residual", C.c_void_p), ("ldr", C.c_int64), ("pre_out", C.c_void_p), ("store_pre", C.c_int32)]
 
 
 class UNetConfig(C.Structure):
@@ -76,6 +77,8 @@ _SIGS = {
     "pcdm_quantize_fp8": ([_P, _P, _L, _I, _I, _L, _L, _F, _P], C.c_int),
     "pcdm_flash_attn_fp8": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _F, _F, _P], C.c_int),
     "pcdm_timestep_embedding": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
+    "pcdm_timestep_embedding_rows": ([_P, _I, _P, _I, _I, _F, _P], C.c_int),
+    "pcdm_time_class_combine": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_small_linear": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "pcdm_assemble_input": ([_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_nchw_f32_to_nhwc_bf16": ([_P, _P, _I, _I, _I, _I, _P], C.c_int),
@@ -101,6 +104,8 @@ _SIGS = {
     "pcdm_unet_workspace_bytes": ([_P, _I, _I, _I, _I], _L),
     "pcdm_unet_workspace_init": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "pcdm_unet_prepare_conditioning": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P], C.c_int),
+    "pcdm_unet_time_table_bytes": ([_P, _I, _I], _L),
+    "pcdm_unet_prepare_timesteps": ([_P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_unet_set_shared_cfg_input": ([_P, _P, _I], C.c_int),
     "pcdm_unet_forward": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "pcdm_pack_linear": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),

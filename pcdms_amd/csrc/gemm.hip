@@ -633,7 +633,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         const BufRsrc rs_o = make_buf_rsrc((const char*)p.out + sh * p.ldo * 2, (uint32_t)((((int64_t)p.M - 1) * p.ldo + ncols_out) * 2));
         const BufRsrc rs_r = make_buf_rsrc(has_res ? (const void*)(p.residual + sh * p.ldr) : (const void*)p.out,
                                            has_res ? (uint32_t)((((int64_t)p.M - 1) * p.ldr + p.N) * 2) : 0u);
-        const float* rowvec_rep = (has_rv && REP) ? p.rowvec + (sh / p.rows_per_batch) * p.ldrv : p.rowvec;
+        const float* rowvec0 = pcdm_gemm_detail::rowvec_base(p);
+        const float* rowvec_rep = (has_rv && REP) ? rowvec0 + (sh / p.rows_per_batch) * p.ldrv : rowvec0;
         const BufRsrc rs_v = make_buf_rsrc(has_rv ? (const void*)rowvec_rep : (const void*)p.out,
                                            has_rv ? (uint32_t)((((int64_t)(p.M - 1) / p.rows_per_batch) * p.ldrv + p.N) * 4) : 0u);
         const BufRsrc rs_vt = make_buf_rsrc(v_tile ? (const void*)p.out2 : (const void*)p.out,
@@ -815,6 +816,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
 #endif
         return;
     }
+    const float* rowvec_g = pcdm_gemm_detail::rowvec_base(p);
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = m0 + wm * WM + j * F + prow;
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                 if (n >= p.N) continue;
                 // unconditional loads (absent operands read zeros): see g_zero32
                 const f32x4 bv = *(const f32x4*)(p.bias ? p.bias + n : (const float*)g_zero32);
-                const f32x4 tv = *(const f32x4*)(p.rowvec ? p.rowvec + (int64_t)bidx * p.ldrv + n : (const float*)g_zero32);
+                const f32x4 tv = *(const f32x4*)(rowvec_g ? rowvec_g + (int64_t)bidx * p.ldrv + n : (const float*)g_zero32);
                 const u16x4 rv = *(const u16x4*)(p.residual ? p.residual + rrow + n : (const u16*)g_zero32);
                 float v[4];
 #pragma unroll
@@ -894,7 +896,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
     // epilogue operands first (unconditional loads; absent ones read zeros, see g_zero32): they return while the slabs are summed
     const f32x4 bv = *(const f32x4*)(p.bias ? p.bias + n : (const float*)g_zero32);
-    const f32x4 tv = *(const f32x4*)(p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_batch) * p.ldrv + n : (const float*)g_zero32);
+    const float* rowvec_g = pcdm_gemm_detail::rowvec_base(p);
+    const f32x4 tv = *(const f32x4*)(rowvec_g ? rowvec_g + (int64_t)(m / p.rows_per_batch) * p.ldrv + n : (const float*)g_zero32);
     const u16x4 rv = *(const u16x4*)(p.residual ? p.residual + (int64_t)(m % p.res_mod) * p.ldr + n : (const u16*)g_zero32);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     // slabs summed in a fixed order, four independent 16-byte loads in flight at a time (a one-load-per-iteration loop
@@ -1042,6 +1045,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.Npad = p->Npad;
     a.bias = p->bias;
     a.rowvec = p->rowvec;
+    a.rowvec_step = p->rowvec ? p->rowvec_step : nullptr;
+    a.rowvec_step_stride = p->rowvec_step_stride;
     a.ldrv = p->ldrv > 0 ? (int)p->ldrv : p->N;
     a.rows_per_batch = p->rows_per_batch;
     a.residual = (const u16*)p->residual;

@@ -17,6 +17,8 @@ struct GemmArgs {
     int M, N, K, Npad;
     const float* bias;
     const float* rowvec;
+    const int32_t* rowvec_step;     // device counter selecting the row-vector block: rowvec + *rowvec_step * rowvec_step_stride (pcdm_gemm_params)
+    int64_t rowvec_step_stride;
     int ldrv;
     int rows_per_batch;
     const u16* residual;
@@ -43,6 +45,10 @@ struct GemmArgs {
 }  // namespace pcdm_gemm_detail
 
 namespace pcdm_gemm_detail {
+// the row-vector block of this launch (one scalar load when a step counter is given)
+__device__ __forceinline__ const float* rowvec_base(const GemmArgs& p) {
+    return (p.rowvec && p.rowvec_step) ? p.rowvec + (int64_t)(*p.rowvec_step) * p.rowvec_step_stride : p.rowvec;
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;
 }

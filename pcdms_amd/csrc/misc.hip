@@ -20,6 +20,31 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t_dev, con
     out[i] = is_cos ? cosf(a) : sinf(a);
 }
 
+// the same for a table of timesteps: row i <- t_dev[i]
+__global__ void timestep_embedding_rows_kernel(const int64_t* __restrict__ t_dev, float* __restrict__ out, int n, int dim, int flip, float shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    const int j = i % dim, half = dim / 2;
+    const float tv = (float)t_dev[i / dim];
+    const int kk = j < half ? j : j - half;
+    const float f = expf(-9.210340371976184f * (float)kk / ((float)half - shift));
+    const float a = tv * f;
+    const bool is_cos = flip ? (j < half) : (j >= half);
+    out[i] = is_cos ? cosf(a) : sinf(a);
+}
+
+// out[(i * B + b) * D + d] = bf16( silu( emb_t[i * D + d] + cls[b * D + d] ) )   (cls may be NULL)
+__global__ void time_class_combine_kernel(const float* __restrict__ emb_t, const float* __restrict__ cls, u16* __restrict__ out, int n, int B, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * B * D) return;
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int b = (int)(r % B), st = (int)(r / B);
+    float v = emb_t[(int64_t)st * D + d];
+    if (cls) v += cls[(int64_t)b * D + d];
+    out[i] = f2bf(silu_f(v));
+}
+
 // y[b, n] = act_out( sum_k act_in(x[b,k]) W[n,k] + bias[n] ) + add[b,n]; one wave per n.
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const u16* __restrict__ w,
                                                            const float* __restrict__ bias,
@@ -341,6 +366,20 @@ extern "C" int pcdm_timestep_embedding(const int64_t* t_dev, const int32_t* step
     if (!t_dev || !out || B <= 0 || dim <= 0 || dim % 2) return -1;
     PCDM_LAUNCH(timestep_embedding_kernel, grid1d((int64_t)B * dim, 256), dim3(256), 0, (hipStream_t)s, t_dev, step_dev,
                 out, B, dim, flip_sin_to_cos, shift);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_timestep_embedding_rows(const int64_t* t_dev, int n, float* out, int dim, int flip_sin_to_cos, float shift, pcdm_stream_t s) {
+    if (!t_dev || !out || n <= 0 || dim <= 0 || dim % 2) return -1;
+    PCDM_LAUNCH(timestep_embedding_rows_kernel, grid1d((int64_t)n * dim, 256), dim3(256), 0, (hipStream_t)s, t_dev, out, n, dim, flip_sin_to_cos, shift);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_time_class_combine(const float* emb_t, const float* cls, void* out_bf16, int n, int B, int D, pcdm_stream_t s) {
+    if (!emb_t || !out_bf16 || n <= 0 || B <= 0 || D <= 0) return -1;
+    PCDM_LAUNCH(time_class_combine_kernel, grid1d((int64_t)n * B * D, 256), dim3(256), 0, (hipStream_t)s, emb_t, cls, (u16*)out_bf16, n, B, D);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -57,6 +57,8 @@ struct GnSrc {
     int ldp;
     const float* bias;      // [>= C1] or NULL
     const float* rowvec;    // [B][ldrv] or NULL (the time-embedding projection row of the batch entry)
+    const int32_t* rowvec_step;   // optional device step counter: block rowvec + *rowvec_step * rowvec_step_stride (pcdm_gemm_params)
+    int64_t rowvec_step_stride;
     int ldrv;
     const u16* residual;    // [M][ldr] or NULL
     int ldr;
@@ -71,8 +73,9 @@ __device__ __forceinline__ u16x8 gn_src_load(const GnSrc& s, int b, int64_t row,
     // operands first (unconditional loads; absent ones read zeros), then the slabs in their fixed order, four in flight at a time
     const f32x4 b0 = *(const f32x4*)(s.bias ? s.bias + c : (const float*)g_gn_zero32);
     const f32x4 b1 = *(const f32x4*)(s.bias ? s.bias + c + 4 : (const float*)g_gn_zero32);
-    const f32x4 t0 = *(const f32x4*)(s.rowvec ? s.rowvec + (int64_t)b * s.ldrv + c : (const float*)g_gn_zero32);
-    const f32x4 t1 = *(const f32x4*)(s.rowvec ? s.rowvec + (int64_t)b * s.ldrv + c + 4 : (const float*)g_gn_zero32);
+    const float* rvb = (s.rowvec && s.rowvec_step) ? s.rowvec + (int64_t)(*s.rowvec_step) * s.rowvec_step_stride : s.rowvec;
+    const f32x4 t0 = *(const f32x4*)(rvb ? rvb + (int64_t)b * s.ldrv + c : (const float*)g_gn_zero32);
+    const f32x4 t1 = *(const f32x4*)(rvb ? rvb + (int64_t)b * s.ldrv + c + 4 : (const float*)g_gn_zero32);
     const u16x8 rv = *(const u16x8*)(s.residual ? s.residual + row * s.ldr + c : (const u16*)g_gn_zero32);
     const float* wp = s.part + row * s.ldp + c;
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
@@ -911,7 +914,8 @@ extern "C" int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* p, const void* x2
     GnSrc src{};
     src.x1 = (const u16*)p->pre_out; src.C1 = C1; src.x2 = (const u16*)x2; src.C2 = C2;
     src.part = p->part; src.S = p->split_k; src.ldp = p->Npad; src.slab = (int64_t)p->M * p->Npad;
-    src.bias = p->bias; src.rowvec = p->rowvec; src.ldrv = (int)p->ldrv; src.residual = (const u16*)p->residual; src.ldr = (int)p->ldr;
+    src.bias = p->bias; src.rowvec = p->rowvec; src.ldrv = (int)p->ldrv;
+    src.rowvec_step = p->rowvec ? p->rowvec_step : nullptr; src.rowvec_step_stride = p->rowvec_step_stride; src.residual = (const u16*)p->residual; src.ldr = (int)p->ldr;
     src.pre_out = p->store_pre ? (u16*)p->pre_out : nullptr;   // (the two-kernel path writes the buffer whatever the flag)
     return gn_launch(src, B, HW, groups, eps, gamma, beta, fuse_silu, y, ws, (hipStream_t)s, (u16*)p->pre_out);
 }

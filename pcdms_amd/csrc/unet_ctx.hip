@@ -50,7 +50,13 @@ struct pcdm_unet {
     // per WORKSPACE: what the last prepare_conditioning on it was given -- the shape, n0 = leading batch entries with an all-zero context, pose_b.
     // forward() takes n0 from the workspace it runs on (a host may alternate workspaces / batch shapes on one context) and refuses a
     // workspace whose conditioning was never prepared or was prepared for another batch / pose layout
-    std::map<const void*, std::tuple<int, int, int, int, int, int, int>> cond_of_ws;   // {B, h, w, L, n0, pose_b, shared CFG halves}
+    struct WsCond {
+        int B = 0, h = 0, w = 0, L = 0, n0 = 0, pose_b = 0, shared = 0;
+        const float* time_table = nullptr;   // [steps][B][sum Cout] fp32 (pcdm_unet_prepare_timesteps), caller-owned
+        int time_steps = 0;
+        const int64_t* time_t_dev = nullptr;
+    };
+    std::map<const void*, WsCond> cond_of_ws;
     std::string err;
 };
 
@@ -176,6 +182,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles only)
         float ln_eps = 0.f;
         int dup_rows = 0;   // pcdm_gemm_params.dup_rows
+        const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride
+        int64_t rowvec_step_stride = 0;
         int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
     };
     // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
@@ -213,6 +221,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.ldo2 = g.ldo2;
         p.zero_rows = g.zero_rows;
         p.dup_rows = g.dup_rows;
+        p.rowvec_step = g.rowvec ? g.rowvec_step : nullptr;
+        p.rowvec_step_stride = g.rowvec_step_stride;
         const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : (g.dup_rows ? 2 : 0)};
         auto it = u->tiles.find(key);
         if (it != u->tiles.end()) {
@@ -231,6 +241,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
             memset(&pend, 0, sizeof(pend));
             pend.part = p.ws; pend.split_k = p.split_k; pend.M = M; pend.N = w->N; pend.Npad = w->Npad;
             pend.bias = p.bias; pend.rowvec = p.rowvec; pend.ldrv = g.rowvec ? (g.ldrv ? g.ldrv : w->N) : 0;
+            pend.rowvec_step = p.rowvec_step; pend.rowvec_step_stride = p.rowvec_step_stride;
             pend.residual = p.residual; pend.ldr = p.ldr;
             pend.pre_out = out; pend.store_pre = g.defer == 1;
             pend_out = out;
@@ -454,7 +465,9 @@ extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w,
     int n0 = zero_ctx_batches;
     if (n0 < 0 || n0 > B) return -1;
     if (n0 == B) n0 = B > 1 ? B - 1 : 0;
-    u->cond_of_ws[workspace] = std::make_tuple(B, h, w, L, n0, pose ? pose_b : 0, 0);
+    pcdm_unet::WsCond wc;
+    wc.B = B; wc.h = h; wc.w = w; wc.L = L; wc.n0 = n0; wc.pose_b = pose ? pose_b : 0;
+    u->cond_of_ws[workspace] = wc;   // (also drops a time table prepared for the previous conditioning: the class embedding changed)
     if (c.class_embed) {
         if (!class_labels) return -1;
         const PW *c1 = R.pw("class_embedding.linear_1"), *c2 = R.pw("class_embedding.linear_2");
@@ -497,8 +510,69 @@ extern "C" int pcdm_unet_set_shared_cfg_input(pcdm_unet* u, void* workspace, int
     if (!u) return -1;
     auto it = u->cond_of_ws.find(workspace);
     if (it == u->cond_of_ws.end()) return -1;
-    if (shared && (std::get<0>(it->second) % 2 || getenv_off("PCDM_SHARE_CFG_PREFIX"))) shared = 0;
-    std::get<6>(it->second) = shared ? 1 : 0;
+    if (shared && (it->second.B % 2 || getenv_off("PCDM_SHARE_CFG_PREFIX"))) shared = 0;
+    it->second.shared = shared ? 1 : 0;
+    return 0;
+}
+
+// The time / class embedding MLPs and every ResnetBlock2D.time_emb_proj for ALL steps of a timestep table (they depend on the timestep and
+// the class labels only): once per sampling call, after pcdm_unet_prepare_conditioning on the same workspace, instead of five launches
+// per denoise step.  `table` is caller-owned device memory of pcdm_unet_time_table_bytes(u, n, B) bytes (the table proper, then the
+// scratch of this call); pcdm_unet_forward calls on this workspace that pass the SAME t_dev together with a device step counter then pick
+// their block by that counter (pcdm_gemm_params.rowvec_step).  Same per-row arithmetic as the per-step launches: bit-identical.
+extern "C" int64_t pcdm_unet_time_table_bytes(const pcdm_unet* u, int n, int B) {
+    if (!u || n <= 0 || B <= 0) return -1;
+    int temb_n = 0;
+    temb_offsets(u->cfg, &temb_n);
+    const int64_t C0 = u->cfg.block_out_channels[0], D = 4 * C0;
+    return round_up((int64_t)n * B * temb_n * 4, kAlign) + round_up((int64_t)n * C0 * 4, kAlign) + 2 * round_up((int64_t)n * D * 4, kAlign) +
+           round_up((int64_t)n * B * D * 2, kAlign);
+}
+
+extern "C" int pcdm_unet_prepare_timesteps(pcdm_unet* u, const int64_t* t_dev, int n, void* table, void* workspace, pcdm_stream_t s) {
+    if (!u || !t_dev || n <= 0 || !table || !workspace) return -1;
+    auto it = u->cond_of_ws.find(workspace);
+    if (it == u->cond_of_ws.end()) { u->err = "pcdm_unet_prepare_conditioning has not run on this workspace"; return -1; }
+    if (getenv_off("PCDM_TIME_TABLE")) return 0;
+    const pcdm_unet_config& c = u->cfg;
+    const int B = it->second.B;
+    if (make_plan(u, B, it->second.h, it->second.w, it->second.L)) return -1;
+    Run R{u, (char*)workspace, s};
+    int temb_n = 0;
+    temb_offsets(c, &temb_n);
+    const int64_t C0 = c.block_out_channels[0], D = 4 * C0;
+    char* base = (char*)table;
+    float* tab = (float*)base;                      base += round_up((int64_t)n * B * temb_n * 4, kAlign);
+    float* t_emb = (float*)base;                    base += round_up((int64_t)n * C0 * 4, kAlign);
+    float* e1 = (float*)base;                       base += round_up((int64_t)n * D * 4, kAlign);
+    float* emb_t = (float*)base;                    base += round_up((int64_t)n * D * 4, kAlign);
+    void* emb_bf = base;
+    const PW *t1 = R.pw("time_embedding.linear_1"), *t2 = R.pw("time_embedding.linear_2"), *tp = R.pw("time_emb_proj");
+    if (R.rc) return R.rc;
+    R.chk(pcdm_timestep_embedding_rows(t_dev, n, t_emb, (int)C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding_rows");
+    for (int r0 = 0; r0 < n; r0 += 32) {   // (pcdm_small_linear takes <= 32 rows; rows are independent)
+        const int nr = n - r0 < 32 ? n - r0 : 32;
+        R.chk(pcdm_small_linear(t_emb + (int64_t)r0 * C0, t1->w, t1->bias, nullptr, e1 + (int64_t)r0 * D, nr, t1->K, t1->N, 0, 1, s), "pcdm_small_linear");
+        R.chk(pcdm_small_linear(e1 + (int64_t)r0 * D, t2->w, t2->bias, nullptr, emb_t + (int64_t)r0 * D, nr, t2->K, t2->N, 0, 0, s), "pcdm_small_linear");
+    }
+    R.chk(pcdm_time_class_combine(emb_t, c.class_embed ? R.buf<float>("cls2") : nullptr, emb_bf, n, B, (int)D, s), "pcdm_time_class_combine");
+    {   // the SAME tile as the per-step launch (M = B rows): identical bits
+        pcdm_gemm_params p;
+        memset(&p, 0, sizeof(p));
+        p.a = emb_bf; p.lda = D; p.c1 = tp->K;
+        p.w = tp->w; p.M = n * B; p.N = tp->N; p.K = tp->K; p.Npad = tp->Npad;
+        p.bias = tp->bias;
+        p.rows_per_batch = 1;
+        p.epilogue = PCDM_EPI_NCHW_F32;
+        p.out = tab; p.ldo = tp->N;
+        auto tk = u->tiles.find(TileKey{0, B, tp->Npad, tp->K, 0, 0, 0, PCDM_EPI_NCHW_F32, 0, 0, 0});
+        p.tile = (tk != u->tiles.end() && tk->second.second <= 1) ? tk->second.first : 8;
+        R.chk(pcdm_gemm(&p, s), "pcdm_gemm (time_emb_proj table)");
+    }
+    if (R.rc) return R.rc;
+    it->second.time_table = tab;
+    it->second.time_steps = n;
+    it->second.time_t_dev = t_dev;
     return 0;
 }
 
@@ -515,18 +589,20 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     int temb_n = 0;
     const std::map<std::string, int> toff = temb_offsets(c, &temb_n);
     const auto cit = u->cond_of_ws.find(workspace);
-    if (cit == u->cond_of_ws.end() || std::make_tuple(B, h, w, L) != std::make_tuple(std::get<0>(cit->second), std::get<1>(cit->second), std::get<2>(cit->second),
-                                                                                      std::get<3>(cit->second)) || std::get<5>(cit->second) != pose_b) {
+    if (cit == u->cond_of_ws.end() || cit->second.B != B || cit->second.h != h || cit->second.w != w || cit->second.L != L || cit->second.pose_b != pose_b) {
         u->err = cit == u->cond_of_ws.end() ? "pcdm_unet_prepare_conditioning has not run on this workspace"
                                             : "this workspace's conditioning was prepared for another shape / pose_b";
         return -1;
     }
-    const int n0 = std::get<4>(cit->second);
-    const bool shared = std::get<6>(cit->second) != 0;   // the CFG halves share conv_in / the first norm1 / the first conv1's contraction
+    const int n0 = cit->second.n0;
+    const bool shared = cit->second.shared != 0;   // the CFG halves share conv_in / the first norm1 / the first conv1's contraction
 
-    // ---- 1. time / class embedding (ref :661-708)
-    R.chk(pcdm_timestep_embedding(t_dev, step_dev, R.buf<float>("t_emb"), B, C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding");
-    {
+    // ---- 1. time / class embedding (ref :661-708): from the per-call table when one was prepared for this timestep table, else five launches
+    const bool use_table = cit->second.time_table && step_dev && cit->second.time_t_dev == t_dev;
+    const int32_t* rv_step = use_table ? step_dev : nullptr;
+    const int64_t rv_stride = use_table ? (int64_t)B * temb_n : 0;
+    if (!use_table) {
+        R.chk(pcdm_timestep_embedding(t_dev, step_dev, R.buf<float>("t_emb"), B, C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding");
         const PW *t1 = R.pw("time_embedding.linear_1"), *t2 = R.pw("time_embedding.linear_2");
         if (R.rc) return R.rc;
         R.chk(pcdm_small_linear(R.buf<float>("t_emb"), t1->w, t1->bias, nullptr, R.buf<float>("e1"), B, t1->K, t1->N, 0, 1, s), "pcdm_small_linear");
@@ -539,7 +615,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         g.epilogue = PCDM_EPI_NCHW_F32;
         R.gemm(R.buf("emb_bf"), temb_dim, B, R.pw("time_emb_proj"), R.buf("temb"), g);   // every ResnetBlock2D.time_emb_proj in one launch
     }
-    const float* temb = R.buf<float>("temb");
+    const float* temb = use_table ? cit->second.time_table : R.buf<float>("temb");
 
     auto chk_gn_half = [&](const void* x1, int C1, int Bs, int HW_, float e, const float* gamma, const float* beta) {
         R.groupnorm(x1, C1, nullptr, 0, Bs, HW_, e, gamma, beta, 1, R.buf("gn"));
@@ -552,6 +628,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         Run::G g;
         g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = hh; g.Wo = ww;
         g.rowvec = temb + toff.at(p); g.ldrv = temb_n; g.rows_per_batch = HW_;
+        g.rowvec_step = rv_step; g.rowvec_step_stride = rv_stride;
         if (shared_in) {   // the CFG halves still have the same x1: norm1 and conv1's contraction once, two epilogues
             const int Bs = B / 2, Ms = Bs * HW_;
             chk_gn_half(x1, C1, Bs, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"));

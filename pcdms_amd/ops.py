@@ -69,7 +69,8 @@ class DeferredGemm:
     ``groupnorm`` takes this object as its first source (``pcdm_groupnorm_splitk``): it reduces while it loads, and writes ``out`` iff
     ``store`` (something else -- a residual, a skip -- reads the tensor later).  Nothing else may touch the split-K workspace in between."""
 
-    __slots__ = ("part", "split_k", "M", "N", "Npad", "bias", "rowvec", "ldrv", "rpb", "residual", "ldr", "out", "store", "keep")
+    __slots__ = ("part", "split_k", "M", "N", "Npad", "bias", "rowvec", "ldrv", "rowvec_step", "rowvec_step_stride", "rpb", "residual", "ldr", "out",
+                 "store", "keep")
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -106,6 +107,7 @@ def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor
         sp = _lib.GnSplitKSrc()
         sp.part, sp.split_k, sp.M, sp.N, sp.Npad = d.part, d.split_k, d.M, d.N, d.Npad
         sp.bias, sp.rowvec, sp.ldrv, sp.residual, sp.ldr = d.bias, d.rowvec, d.ldrv, d.residual, d.ldr
+        sp.rowvec_step, sp.rowvec_step_stride = d.rowvec_step, d.rowvec_step_stride
         sp.pre_out, sp.store_pre = _ptr(_c(d.out, BF16)), int(d.store)
         rc = _lib.lib().pcdm_groupnorm_splitk(C.byref(sp), _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta), int(silu),
                                              _ptr(out), _ptr(ws), _stream(out))
@@ -232,7 +234,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
-         defer_reduce: Optional[bool] = None, dup_rows: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
+         defer_reduce: Optional[bool] = None, dup_rows: int = 0, rowvec_step: Optional[torch.Tensor] = None,
+         rowvec_step_stride: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
@@ -245,6 +248,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     GroupNorm; ``False``-but-not-``None`` i.e. ``0``: only the next GroupNorm reads it): when the configuration in use splits K, skip the
     reduce launch and return a ``DeferredGemm`` for ``ops.groupnorm`` to consume.  The caller promises that the very next user of the
     result is that GroupNorm and that no other split-K GEMM runs in between.  ``None``: never defer.
+
+    ``rowvec_step`` (device int32 counter) / ``rowvec_step_stride`` (floats): the row-vector block in use is ``rowvec + *rowvec_step *
+    rowvec_step_stride`` -- the per-step slice of a table that holds the time-embedding projections of every denoise step.
 
     ``dup_rows`` (conv only): ``out`` has ``M + dup_rows`` rows; rows ``m + dup_rows`` get the same contraction with THEIR row-vector /
     residual rows (``pcdm_gemm_params.dup_rows``: the CFG-shared prefix of the UNet)."""
@@ -282,6 +288,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         assert rowvec.dtype == torch.float32 and rowvec.shape[-1] == pw.N and rowvec.stride(-1) == 1
         p.rowvec = _ptr(rowvec)
         p.ldrv = rowvec.stride(0)
+        if rowvec_step is not None:
+            assert rowvec_step.dtype == torch.int32 and rowvec_step.device == rowvec.device
+            p.rowvec_step, p.rowvec_step_stride = _ptr(rowvec_step), int(rowvec_step_stride)
     if residual is not None:
         _c(residual, BF16)
         p.residual = _ptr(residual)
@@ -317,8 +326,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
                 and (rowvec is None or (rows_per_batch and M % rows_per_batch == 0)) and out.is_contiguous() and out.shape == (M, pw.N):
             p.defer_reduce = 1
             deferred = DeferredGemm(part=ws.data_ptr(), split_k=split, M=M, N=pw.N, Npad=pw.Npad, bias=p.bias, rowvec=p.rowvec,
-                                    ldrv=p.ldrv if rowvec is not None else 0, rpb=p.rows_per_batch, residual=p.residual, ldr=p.ldr, out=out,
-                                    store=bool(defer_reduce), keep=(ws, rowvec, residual, pw))
+                                    ldrv=p.ldrv if rowvec is not None else 0, rowvec_step=p.rowvec_step, rowvec_step_stride=p.rowvec_step_stride,
+                                    rpb=p.rows_per_batch, residual=p.residual, ldr=p.ldr, out=out,
+                                    store=bool(defer_reduce), keep=(ws, rowvec, residual, pw, rowvec_step))
     if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -601,6 +611,23 @@ def timestep_embedding(t_dev: torch.Tensor, step_dev: Optional[torch.Tensor], ou
     B, dim = out.shape
     _chk(_lib.lib().pcdm_timestep_embedding(_ptr(t_dev), _ptr(step_dev), _ptr(out), B, dim, int(flip), shift,
                                             _stream(out)), "pcdm_timestep_embedding")
+    return out
+
+
+def timestep_embedding_rows(t_dev: torch.Tensor, out: torch.Tensor, flip: bool = True, shift: float = 0.0) -> torch.Tensor:
+    """out[i, :] = Timesteps(t_dev[i]) for a whole timestep table (fp32 [n, dim])."""
+    assert t_dev.dtype == torch.int64 and out.dtype == torch.float32 and out.shape[0] == t_dev.numel() and out.is_contiguous()
+    _chk(_lib.lib().pcdm_timestep_embedding_rows(_ptr(t_dev), t_dev.numel(), _ptr(out), out.shape[1], int(flip), shift, _stream(out)),
+         "pcdm_timestep_embedding_rows")
+    return out
+
+
+def time_class_combine(emb_t: torch.Tensor, cls: Optional[torch.Tensor], out: torch.Tensor, B: int) -> torch.Tensor:
+    """out[i * B + b] = bf16(silu(emb_t[i] + cls[b])): emb_t fp32 [n, D], cls fp32 [B, D] or None, out bf16 [n * B, D]."""
+    n, D = emb_t.shape
+    _c(emb_t, torch.float32); _c(out, BF16)
+    assert out.shape == (n * B, D) and (cls is None or (_c(cls, torch.float32).shape == (B, D)))
+    _chk(_lib.lib().pcdm_time_class_combine(_ptr(emb_t), _ptr(cls), _ptr(out), n, B, D, _stream(out)), "pcdm_time_class_combine")
     return out
 
 

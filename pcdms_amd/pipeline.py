@@ -335,8 +335,10 @@ class Stage2_InpaintDiffusionPipeline:
         if mask is not None:
             st["mask"].copy_(mask)
         st["masked"].copy_(masked)
-        st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0, shared_cfg_input=shared_halves)
         st["timesteps"].copy_(timesteps.to(dev))
+        # (with the timestep table: the time / class embedding MLPs and every time_emb_proj for ALL steps, once per call)
+        st["cond"] = unet.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0, shared_cfg_input=shared_halves,
+                                               timesteps=st["timesteps"])
         st["coef"].copy_(self.scheduler.coefficient_table(device=dev) if unipc else self.scheduler.coefficient_table(eta, device=dev))
         st["g"] = g
         if st.get("gr", guidance_rescale) != guidance_rescale:
@@ -367,6 +369,7 @@ class Stage2_InpaintDiffusionPipeline:
                 st["c_tuned"] = (id(self._ctx), w_gen)
             st["pose_b"] = self._ctx.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0,
                                                           shared_cfg_input=st["cond"].shared_halves)
+            self._ctx.prepare_timesteps(st["timesteps"], B, h, w)
             st["eps_c"] = st.get("eps_c") if st.get("eps_c") is not None and st["eps_c"].shape[0] == B else \
                 torch.empty(B, unet.config.out_channels, h, w, dtype=torch.float32, device=dev)
             st["ctx"] = self._ctx

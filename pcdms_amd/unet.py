@@ -32,6 +32,7 @@ from ._module import ModuleSurface
 from .ops import BF16, PackedWeight
 
 SHARE_CFG_PREFIX = os.environ.get("PCDM_SHARE_CFG_PREFIX", "1") != "0"   # A/B switch (tools/README.md)
+TIME_TABLE = os.environ.get("PCDM_TIME_TABLE", "1") != "0"               # A/B switch: time embeddings of all steps with the conditioning
 
 _DEFAULT_CONFIG: Dict[str, Any] = dict(
     sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
@@ -98,12 +99,14 @@ def _as_tuple(v, n):
 class Conditioning:
     """Step-invariant part of one sampling call (``prepare_conditioning``): views of the model's scratch buffers."""
 
-    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv", "shared_halves")
+    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv", "shared_halves", "temb_all", "temb_steps")
 
     def __init__(self, gen: int, B: int, h: int, w: int, L: int):
         self.gen, self.B, self.h, self.w, self.L = gen, B, h, w, L
         self.n0 = 0                      # leading batch entries with an all-zero context (cross-attention skipped there)
         self.shared_halves = False       # batch entries b and b + B/2 have the same sample / mask / masked latents / pose (the CFG halves)
+        self.temb_all: Optional[torch.Tensor] = None   # fp32 [steps, B, sum Cout]: every resnet's time_emb_proj(silu(emb)) for EVERY step
+        self.temb_steps: Optional[torch.Tensor] = None  # the timestep table it was computed for
         self.cls_emb: Optional[torch.Tensor] = None
         self.pose_nhwc: Optional[torch.Tensor] = None
         self.kv: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -387,7 +390,8 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
     # ------------------------------------------------------------------ step-invariant conditioning
     def prepare_conditioning(self, B: int, h: int, w: int, encoder_hidden_states: torch.Tensor,
                              class_labels: Optional[torch.Tensor], my_pose_cond: Optional[torch.Tensor],
-                             zero_ctx_batches: Optional[int] = None, shared_cfg_input: bool = False) -> "Conditioning":
+                             zero_ctx_batches: Optional[int] = None, shared_cfg_input: bool = False,
+                             timesteps: Optional[torch.Tensor] = None) -> "Conditioning":
         """Everything of one forward that does not depend on the timestep or the latents:
         class embedding (ref :688-708), NHWC pose feature (ref :742) and the cross-attention K / V^T of the context for all
         16 transformer blocks.  Results live in shape-keyed scratch buffers (static addresses: a captured hipGraph stays valid
@@ -403,7 +407,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         pose feature -- the two classifier-free-guidance halves (ref stage2_inpaint_pipeline.py:499-501: ``torch.cat([latents] * 2)``,
         one mask / masked latents / pose for both).  Only ``class_labels`` and the context differ between them, and those enter behind
         ``conv_in``, the first GroupNorm and the contraction of the first ``conv1``: that prefix is then computed for B/2 entries and
-        written for both halves (``pcdm_gemm_params.dup_rows``) -- the same arithmetic, executed once."""
+        written for both halves (``pcdm_gemm_params.dup_rows``) -- the same arithmetic, executed once.
+
+        ``timesteps`` (device int64 table of the whole schedule): the time / class embedding MLPs and all 22 ``time_emb_proj`` rows depend
+        on the timestep and the class labels only, so they are computed HERE for every step (one GEMM with M = steps x B rows) instead of
+        five launches per denoise step; a forward that is given the table's device step counter (``_forward_nhwc(..., step_dev)``) picks
+        its block through ``pcdm_gemm_params.rowvec_step``.  Same per-row arithmetic as the per-step launches (bit-identical)."""
         if self._w is None:
             self._pack()
         W, cfg, dev = self._w, self.config, self._device
@@ -462,7 +471,34 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 cond.kv[p] = (k8, vt8.view(Bc, c, L16))
             else:
                 cond.kv[p] = (kbuf, vtbuf)
+        if timesteps is not None and TIME_TABLE:
+            self._time_table(cond, timesteps)
         return cond
+
+    def _time_table(self, cond: "Conditioning", timesteps: torch.Tensor) -> None:
+        """cond.temb_all[i, b, :] = concat over resnets of time_emb_proj(silu(time_embedding(t_i) + class_embedding(b))) (ref :661-708 and every
+        ResnetBlock2D's ``time_emb_proj(act(temb))``), for all steps i of the table: 2 + 2 x ceil(n / 32) + 2 launches per sampling call."""
+        W, cfg, dev, B = self._w, self.config, self._device, cond.B
+        boc = self._boc
+        temb_dim = boc[0] * 4
+        ts = timesteps.reshape(-1)
+        if ts.dtype != torch.int64 or ts.device != dev:
+            ts = ts.to(dev, torch.int64)
+        n = ts.numel()
+        t_emb = ops.timestep_embedding_rows(ts, self._buf("tt_emb", (n, boc[0]), torch.float32), cfg.flip_sin_to_cos, float(cfg.freq_shift))
+        e1 = self._buf("tt_e1", (n, temb_dim), torch.float32)
+        emb_t = self._buf("tt_emb_t", (n, temb_dim), torch.float32)
+        for r0 in range(0, n, 32):   # (pcdm_small_linear takes <= 32 rows; rows are independent)
+            r1 = min(n, r0 + 32)
+            ops.small_linear(t_emb[r0:r1], W["time1"][0], W["time1"][1], e1[r0:r1], act_out=True)
+            ops.small_linear(e1[r0:r1], W["time2"][0], W["time2"][1], emb_t[r0:r1])
+        emb_bf = ops.time_class_combine(emb_t, cond.cls_emb, self._buf("tt_emb_bf", (n * B, temb_dim)), B)
+        # the SAME tile as the per-step launch (M = B rows) uses: every output element is then the same sequence of MFMAs -> identical bits
+        tile, split = ops._TUNED.get((B, W["temb"].Npad, W["temb"].K, 0, 0, 0, ops.EPI_NCHW_F32, False, False), (8, 1))
+        out = self._buf("tt_all", (n * B, W["temb_n"]), torch.float32)
+        ops.gemm(emb_bf, W["temb"], out, rows_per_batch=1, epilogue=ops.EPI_NCHW_F32, tile=tile if split <= 1 else 8)
+        cond.temb_all = out.view(n, B, W["temb_n"])
+        cond.temb_steps = ts
 
     def _conditioning_for(self, B, h, w, ehs, class_labels, pose, zero_ctx_batches: Optional[int] = None) -> "Conditioning":
         """Bare ``forward`` callers (the reference pipeline's own loop): reuse the last conditioning
@@ -556,17 +592,25 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 t_dev = t_dev.to(dev, torch.int64)
         else:
             t_dev = torch.tensor([int(timestep)], dtype=torch.int64, device=dev)
-        t_emb = ops.timestep_embedding(t_dev, step_dev, self._buf("t_emb", (B, boc[0]), torch.float32),
-                                       cfg.flip_sin_to_cos, float(cfg.freq_shift))
         cls_emb, pose_nhwc, kv, L, nzero = cond.cls_emb, cond.pose_nhwc, cond.kv, cond.L, cond.n0
-        e1 = ops.small_linear(t_emb, W["time1"][0], W["time1"][1], self._buf("e1", (B, temb_dim), torch.float32), act_out=True)
-        # emb = time_emb + class_emb is only ever consumed as silu(emb) (ResnetBlock2D): apply it here, once
-        emb_act = ops.small_linear(e1, W["time2"][0], W["time2"][1], self._buf("emb", (B, temb_dim), torch.float32),
-                                   add=cls_emb, act_out=2 if cls_emb is not None else 1)
-        # every ResnetBlock2D.time_emb_proj(silu(emb)) in one launch
-        emb_bf = ops.f32_to_bf16(emb_act, self._buf("emb_bf", (B, temb_dim)))
-        temb = ops.gemm(emb_bf, W["temb"], self._buf("temb", (B, W["temb_n"]), torch.float32), rows_per_batch=1,
-                        epilogue=ops.EPI_NCHW_F32)                      # fp32 [B, 20160] (rows_per_batch = 1: "NCHW" == row-major)
+        rv_step, rv_stride = None, 0
+        if cond.temb_all is not None and step_dev is not None and torch.is_tensor(timestep) and timestep.data_ptr() == cond.temb_steps.data_ptr() \
+                and timestep.numel() == cond.temb_steps.numel():
+            # the time-embedding projections of every step were computed with the conditioning (prepare_conditioning(timesteps=...)): this
+            # step's block is picked inside the kernels by the device step counter -- nothing to launch here
+            temb = cond.temb_all[0]
+            rv_step, rv_stride = step_dev, cond.temb_all.stride(0)
+        else:
+            t_emb = ops.timestep_embedding(t_dev, step_dev, self._buf("t_emb", (B, boc[0]), torch.float32),
+                                           cfg.flip_sin_to_cos, float(cfg.freq_shift))
+            e1 = ops.small_linear(t_emb, W["time1"][0], W["time1"][1], self._buf("e1", (B, temb_dim), torch.float32), act_out=True)
+            # emb = time_emb + class_emb is only ever consumed as silu(emb) (ResnetBlock2D): apply it here, once
+            emb_act = ops.small_linear(e1, W["time2"][0], W["time2"][1], self._buf("emb", (B, temb_dim), torch.float32),
+                                       add=cls_emb, act_out=2 if cls_emb is not None else 1)
+            # every ResnetBlock2D.time_emb_proj(silu(emb)) in one launch
+            emb_bf = ops.f32_to_bf16(emb_act, self._buf("emb_bf", (B, temb_dim)))
+            temb = ops.gemm(emb_bf, W["temb"], self._buf("temb", (B, W["temb_n"]), torch.float32), rows_per_batch=1,
+                            epilogue=ops.EPI_NCHW_F32)                      # fp32 [B, 20160] (rows_per_batch = 1: "NCHW" == row-major)
 
         # Split-K convolutions (levels 1-3: M <= 11264 rows against K up to 23040) leave their fp32 partial slabs for the GroupNorm that
         # always follows -- conv1 -> norm2, conv2 / down- / upsampling conv -> the next block's first norm -- which reduces them while it
@@ -582,13 +626,14 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 Bs, Ms = B // 2, (B // 2) * HW_
                 n1 = ops.groupnorm(x1[:Ms], None, Bs, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin))[:Ms], ws)
                 h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=dict(B=Bs, Hi=hh, Wi=ww, Ho=hh, Wo=ww), rowvec=tv,
-                              rows_per_batch=HW_, dup_rows=Ms)
+                              rows_per_batch=HW_, dup_rows=Ms, rowvec_step=rv_step, rowvec_step_stride=rv_stride)
                 cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
             else:
                 n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
                 x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
                 cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
-                h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False)
+                h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False,
+                              rowvec_step=rv_step, rowvec_step_stride=rv_stride)
             n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)

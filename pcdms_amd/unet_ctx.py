@@ -150,6 +150,21 @@ class UNetContext:
         return pose_b
 
     @torch.no_grad()
+    def prepare_timesteps(self, t_dev: torch.Tensor, B: int, h: int, w: int) -> None:
+        """After ``prepare_conditioning``: the time / class embeddings and every ``time_emb_proj`` for ALL steps of the device timestep table
+        ``t_dev`` (``pcdm_unet_prepare_timesteps``); ``forward`` calls that pass the same ``t_dev`` with a step counter then launch nothing for them."""
+        assert t_dev.dtype == torch.int64 and t_dev.is_contiguous() and t_dev.device == self.unet.device
+        n = t_dev.numel()
+        nbytes = _lib.lib().pcdm_unet_time_table_bytes(self._h, n, B)
+        key = ("ttab", n, B)
+        tab = self._ws.get(key)
+        if tab is None:
+            tab = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.unet.device)
+        ws = self.workspace(B, h, w, self._L)
+        self._chk(_lib.lib().pcdm_unet_prepare_timesteps(self._h, t_dev.data_ptr(), n, tab.data_ptr(), ws.data_ptr(), ops._stream(ws)),
+                  "pcdm_unet_prepare_timesteps")
+
+    @torch.no_grad()
     def forward(self, x_in: torch.Tensor, t_dev: torch.Tensor, step_dev: Optional[torch.Tensor], B: int, h: int, w: int, pose_b: int,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_in NHWC bf16 [B, h, w, conv_in.cin]; t_dev int64 device tensor; returns fp32 NCHW eps."""

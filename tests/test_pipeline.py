@@ -438,3 +438,29 @@ def test_cfg_shared_prefix_in_the_sampler(backend, monkeypatch):
        s_img_proj_f=torch.randn(1, L, c3.cross_attention_dim, generator=g).to(dev), gen_t_img_latents=torch.randn(1, 4, h, w, generator=g).to(dev),
        latents=torch.randn(N, 4, h, w, generator=g).to(dev))
     assert not p3._st["cond"].shared_halves
+
+
+def test_time_embedding_table_is_exact(backend, monkeypatch):
+    """The time / class embedding MLPs and all ``time_emb_proj`` rows of EVERY step computed once with the conditioning
+    (``prepare_conditioning(timesteps=...)`` / ``pcdm_unet_prepare_timesteps``; the kernels pick a step's block through
+    ``pcdm_gemm_params.rowvec_step``) instead of five launches per denoise step: same per-row arithmetic on the same tile, so the sampled
+    latents must equal the per-step form (``PCDM_TIME_TABLE=0``) BIT FOR BIT -- Python schedule and C schedule, DDIM and UniPC."""
+    import pcdms_amd.unet as U
+    cfg = UNetConfig.tiny()
+    dev = backend.device
+    N, h, w, L, steps = (1, 8, 8, 4, 2) if backend.is_emu else (2, 16, 24, 9, 5)
+    sd, m = _build(backend, cfg)
+    inp = synth_inputs(cfg, h, w, N, L_img=L)
+    for sched in (DDIMScheduler,) if backend.is_emu else (DDIMScheduler, UniPCMultistepScheduler):
+        outs = {}
+        for table in (True, False):
+            monkeypatch.setattr(U, "TIME_TABLE", table)
+            monkeypatch.setenv("PCDM_TIME_TABLE", "1" if table else "0")
+            for c_sched in (False, True):
+                pipe = Stage2_InpaintDiffusionPipeline(m, sched.from_config(SD21), c_schedule=c_sched)
+                outs[(table, c_sched)] = _call(pipe, inp, dev, N, steps, h, w)
+                assert (pipe._st["cond"].temb_all is not None) == table
+        backend.sync()
+        ref = outs[(False, False)]
+        for k, v in outs.items():
+            assert torch.equal(v, ref), (sched.__name__, k, (v - ref).abs().max())
