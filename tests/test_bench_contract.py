@@ -50,7 +50,11 @@ def test_bench_flags_and_defaults():
         assert env in src
     assert "dist.barrier()" in src and "torch.cuda.synchronize()" in src and "ReduceOp.MAX" in src
     # the oracle is only the cpu_baseline leg / synthetic data generator, never the measured path
-    assert "from oracle.unet import unet_forward" in src.split("def cpu_baseline")[1]
+    # (round 4: the timing runs in a pinned child process, bench.py --cpu-baseline-worker)
+    worker = src.split("def cpu_baseline_worker")[1].split("\ndef ")[0]
+    assert "unet_forward" in worker and "from oracle.unet import" in worker
+    timed = src.split("def timed(")[1].split("elapsed = timed(")[0]
+    assert "oracle" not in timed
 
 
 def test_bench_spawns_its_own_ranks(monkeypatch):
