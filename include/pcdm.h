@@ -282,6 +282,9 @@ int pcdm_unet_set_weight(pcdm_unet* u, const char* name, const void* w_bf16, con
 int pcdm_unet_set_vector(pcdm_unet* u, const char* name, const float* v, int n);
 int pcdm_unet_set_tile(pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source, int residual,
                        int zero_rows, int tile, int split_k);
+/* 1: every attention of the UNet with OCP e4m3 K / V^T / Q / P operands (pcdm_quantize_fp8 + pcdm_flash_attn_fp8; BASELINE.json configs[4]), 0
+ * (default): bf16.  Switch before pcdm_unet_prepare_conditioning (it quantises the context K / V^T) and before capturing a graph. */
+int pcdm_unet_set_attention_fp8(pcdm_unet* u, int on);
 int pcdm_unet_get_tile(const pcdm_unet* u, int ln, int M, int Npad, int K, int conv, int stride, int upsample, int epilogue, int two_source, int residual,
                        int flag, int* tile, int* split_k);
 int64_t pcdm_unet_workspace_bytes(pcdm_unet* u, int B, int h, int w, int L);

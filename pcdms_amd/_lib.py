@@ -100,6 +100,7 @@ _SIGS = {
     "pcdm_unet_set_weight": ([_P, C.c_char_p, _P, _P, _P, _I, _I, _I, _I], C.c_int),
     "pcdm_unet_set_vector": ([_P, C.c_char_p, _P, _I], C.c_int),
     "pcdm_unet_set_tile": ([_P] + [_I] * 13, C.c_int),
+    "pcdm_unet_set_attention_fp8": ([_P, _I], C.c_int),
     "pcdm_unet_get_tile": ([_P] + [_I] * 11 + [C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "pcdm_unet_workspace_bytes": ([_P, _I, _I, _I, _I], _L),
     "pcdm_unet_workspace_init": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),

@@ -57,6 +57,7 @@ struct pcdm_unet {
         const int64_t* time_t_dev = nullptr;
     };
     std::map<const void*, WsCond> cond_of_ws;
+    bool attn_fp8 = false;   // every attention with e4m3 K / V^T / Q / P operands (pcdm_unet_set_attention_fp8; BASELINE.json configs[4])
     std::string err;
 };
 
@@ -286,6 +287,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
 };
 
 int64_t lp8(int64_t v) { return (v + 7) / 8 * 8; }
+int64_t lp16(int64_t v) { return (v + 15) / 16 * 16; }
 
 bool has_cross(const pcdm_unet_config& c, int level) { return c.cross_attn[level] != 0; }
 
@@ -328,6 +330,10 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
         const int cc = std::get<1>(t);
         P.add("k2:" + std::get<0>(t), (int64_t)B * L * cc * 2);
         P.add("vt2:" + std::get<0>(t), (int64_t)B * cc * lp8(L) * 2);
+        // e4m3 copies of the context K / V^T (1 byte per element; key axis padded to 16); laid out whether or not fp8 is switched on, so
+        // that switching does not move the other buffers (a captured graph stays valid)
+        P.add("k2_8:" + std::get<0>(t), (int64_t)B * L * cc);
+        P.add("vt2_8:" + std::get<0>(t), (int64_t)B * cc * lp16(L));
     }
     // ---- per step
     P.add("t_emb", (int64_t)B * C0 * 4);
@@ -339,7 +345,7 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
     int cin_max = 0;
     for (auto& r : resnets(c)) cin_max = std::get<1>(r) > cin_max ? std::get<1>(r) : cin_max;
     // rows x channels never exceed M0 x max(channels at that level): a safe bound is max over levels of M_l * C_l-ish; use per-level maxima
-    int64_t act = 0, act_gn = 0, act_ff = 0, act_qk = 0, act_vt = 0;
+    int64_t act = 0, act_gn = 0, act_ff = 0, act_qk = 0, act_vt = 0, act_vt8 = 0;
     {
         int hh = h, ww = w;
         for (int i = 0; i < n; ++i) {
@@ -355,6 +361,7 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
             act_ff = std::max(act_ff, M * 4 * ci * 2);
             act_qk = std::max(act_qk, M * 2 * ci * 2);
             act_vt = std::max(act_vt, (int64_t)B * ci * lp8((int64_t)hh * ww) * 2);
+            act_vt8 = std::max(act_vt8, (int64_t)B * ci * lp16((int64_t)hh * ww));
             if (i != n - 1) { hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1; }
         }
     }
@@ -363,6 +370,8 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
     P.add("ff", act_ff);
     P.add("qk", act_qk);
     P.add("vt", act_vt);
+    P.add("k8", act_qk / 4);        // e4m3 K of the self-attention in flight: M x C bytes (act_qk = M x 2C x 2 bytes)
+    P.add("vt8", act_vt8);
     {   // skip tensors: one buffer per skip, exact sizes
         int hh = h, ww = w;
         P.add("skip0", M0 * C0 * 2);
@@ -421,6 +430,15 @@ extern "C" int pcdm_unet_set_tile(pcdm_unet* u, int ln, int M, int Npad, int K, 
                                   int residual, int zero_rows, int tile, int split_k) {
     if (!u || tile < 0) return -1;
     u->tiles[TileKey{ln, M, Npad, K, conv, stride, upsample, epilogue, two_source, residual, zero_rows}] = {tile, split_k};
+    return 0;
+}
+
+// Every attention of the UNet (self and cross) with e4m3 operands on the MX-scaled fp8 MFMA (BASELINE.json configs[4]; pcdms_amd's
+// set_attention_precision("fp8")).  Switch BEFORE pcdm_unet_prepare_conditioning (which quantises the context K / V^T) and before capturing.
+extern "C" int pcdm_unet_set_attention_fp8(pcdm_unet* u, int on) {
+    if (!u) return -1;
+    if ((on != 0) != u->attn_fp8) u->cond_of_ws.clear();   // (outstanding conditionings lack / carry the e4m3 copies)
+    u->attn_fp8 = on != 0;
     return 0;
 }
 
@@ -499,6 +517,10 @@ extern "C" int pcdm_unet_prepare_conditioning(pcdm_unet* u, int B, int h, int w,
         g.vt_col0 = cc;
         g.ldo = cc;
         R.gemm(R.buf("ctx"), c.cross_attention_dim, Bc * L, R.pw(p + "kv2"), R.buf("k2:" + p), g);
+        if (u->attn_fp8 && !R.rc) {   // e4m3 copies, once per sampling call (pcdms_amd/unet.py::prepare_conditioning)
+            R.chk(pcdm_quantize_fp8(R.buf("k2:" + p), R.buf("k2_8:" + p), (int64_t)Bc * L, cc, cc, cc, cc, 1.0f, s), "pcdm_quantize_fp8");
+            R.chk(pcdm_quantize_fp8(R.buf("vt2:" + p), R.buf("vt2_8:" + p), (int64_t)Bc * cc, L, (int)lp16(L), lp8(L), lp16(L), 1.0f, s), "pcdm_quantize_fp8");
+        }
     }
     return R.rc;
 }
@@ -671,6 +693,12 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         }
         u16* qk = R.buf<u16>("qk");
         if (R.rc) return nullptr;
+        if (u->attn_fp8) {   // K and V^T quantised once per attention, Q and P inside the kernel (pcdms_amd/unet.py::transformer)
+            R.chk(pcdm_quantize_fp8(qk + cc, R.buf("k8"), M, cc, cc, 2 * cc, cc, 1.0f, s), "pcdm_quantize_fp8");
+            R.chk(pcdm_quantize_fp8(R.buf("vt"), R.buf("vt8"), (int64_t)B * cc, HW_, (int)lp16(HW_), lp8(HW_), lp16(HW_), 1.0f, s), "pcdm_quantize_fp8");
+            R.chk(pcdm_flash_attn_fp8(qk, 2 * cc, R.buf("k8"), cc, R.buf("vt8"), lp16(HW_), R.buf("at"), cc, B, H, HW_, HW_, 0.125f, 1.0f, 1.0f, 5.0f, s),
+                  "pcdm_flash_attn_fp8");
+        } else
         R.chk(pcdm_flash_attn(qk, 2 * cc, qk + cc, 2 * cc, R.buf("vt"), lp8(HW_), R.buf("at"), cc, B, H, HW_, HW_, 0.125f, s), "pcdm_flash_attn");
         {
             Run::G g;
@@ -686,6 +714,10 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             R.gemm_ln(t1 + r0 * cc, cc, M - (int)r0, R.pw(p + "q2"), wl, R.vec(b + "norm2.weight"), R.vec(b + "norm2.bias"), 1e-5f, ln + r0 * cc, q2 + r0 * cc, g);
         }
         if (R.rc) return nullptr;
+        if (u->attn_fp8)
+            R.chk(pcdm_flash_attn_fp8(q2 + r0 * cc, cc, R.buf("k2_8:" + p), cc, R.buf("vt2_8:" + p), lp16(L), at + r0 * cc, cc, B - n0, H, HW_, L, 0.125f, 1.0f,
+                                      1.0f, 5.0f, s), "pcdm_flash_attn_fp8");
+        else
         R.chk(pcdm_flash_attn(q2 + r0 * cc, cc, R.buf("k2:" + p), cc, R.buf("vt2:" + p), lp8(L), at + r0 * cc, cc, B - n0, H, HW_, L, 0.125f, s), "pcdm_flash_attn");
         {
             Run::G g;

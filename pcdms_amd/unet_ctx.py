@@ -21,8 +21,6 @@ class UNetContext:
     def __init__(self, unet: Stage2_InapintUNet2DConditionModel):
         if unet._w is None:
             unet._pack()
-        if unet._attn_fp8:
-            raise NotImplementedError("the C schedule runs the bf16 attention path")
         self.unet = unet
         self._pack_gen = unet._pack_gen
         lib = _lib.lib()
@@ -41,6 +39,8 @@ class UNetContext:
         self._h = lib.pcdm_unet_create(C.byref(cfg))
         if not self._h:
             raise RuntimeError("pcdm_unet_create rejected the topology")
+        self._attn_fp8 = bool(unet._attn_fp8)
+        self._chk(lib.pcdm_unet_set_attention_fp8(self._h, int(self._attn_fp8)), "pcdm_unet_set_attention_fp8")
         self._keep = []       # tensors the context points into
         self._ws = {}
         self._register()
