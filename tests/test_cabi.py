@@ -47,3 +47,39 @@ def test_missing_library_fails_loudly(tmp_path):
     from pcdms_amd import _lib
     with pytest.raises(RuntimeError, match="no fallback"):
         _lib.load(tmp_path / "libpcdm.so")
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors in pcdms_amd/_lib.py against the C structs of include/pcdm.h as gcc lays them out: size and the offset of every
+    field (pcdm_gemm_params grew without a version bump -- an ABI drift between the header and a binding must fail a test, and
+    ``pcdm_version()`` must say 2 for the struct that ends with ``dup_rows``)."""
+    import shutil
+    import subprocess
+
+    from pcdms_amd import _lib
+    from pcdms_amd.build import build_lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    structs = {"pcdm_gemm_params": _lib.GemmParams, "pcdm_gn_splitk_src": _lib.GnSplitKSrc, "pcdm_unet_config": _lib.UNetConfig}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "pcdm.h"}"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-std=c11", "-Wall", "-Werror", str(src), "-o", str(exe)])   # (also: the header is valid C11 on its own)
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(ct), (cname, got[cname], ctypes.sizeof(ct))
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
+    # every field of the header's struct is mirrored (a field added to the header only would shift nothing above but be left unset)
+    hdr = (ROOT / "include" / "pcdm.h").read_text()
+    body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct pcdm_gemm_params {"):hdr.index("} pcdm_gemm_params;")], flags=re.S)
+    names = re.findall(r"(\w+)\s*(?:,|;)", body.split("{", 1)[1])
+    assert names == [f for f, _ in _lib.GemmParams._fields_], (names, [f for f, _ in _lib.GemmParams._fields_])
+    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 2
