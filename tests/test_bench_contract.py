@@ -12,7 +12,8 @@ ROOT = Path(__file__).resolve().parent.parent
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r2_bench_fast_box.json", "r3_bench.json", "r3_bench_fast_box.json", "r3_bench_final_sources.json", "r3_bench_slow_box.json"])
+@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r2_bench_fast_box.json", "r3_bench.json", "r3_bench_fast_box.json", "r3_bench_final_sources.json", "r3_bench_slow_box.json",
+                                  "r4_bench.json", "r4_bench_with_traffic.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = (ROOT / "profiles" / name).read_text().strip().splitlines()[-1]
     d = json.loads(line)
@@ -31,8 +32,16 @@ def test_committed_bench_line_has_the_contract_fields(name):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
     # achieved = algorithmic FLOPs per launch / average launch duration
     assert abs(r["achieved"] - r["alg_gflop_per_launch"] / r["avg_launch_us"] * 1e3)   # GFLOP / us = 1000 TFLOP/s < 0.02 * r["achieved"]
+    if name == "r4_bench_with_traffic.json":   # (the line that quotes the traffic passes of its session: run with --no-cpu-baseline)
+        assert r["traffic"] and r["traffic"] > 1.5 * 48.6e6 and "cpu_baseline" not in d
+        return
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    if name.startswith("r4"):   # round 4: CPU baseline from the pinned child process (thread counts of the host, NUMA map recorded)
+        assert 0 < r["e2e_frac_executed"] < r["e2e_frac"] < 1 and c["config1"]["seconds"] > 0
+        assert str(c["cores"]) in c["per_thread_count"] and c["host"]["numa_nodes"] and "pinned" in c["sample"]
+        assert all(v["tflops_fp32"] > 0 for v in c["per_thread_count"].values())
+        return
     if name.startswith(("r2", "r3")):   # round 2: whole-path fraction, the RCCL world size, the full configs[0] CPU run
         assert 0 < r["e2e_frac"] < 1 and cfg["rccl_world_size"] == d["n_gpus"] and c["config1"]["seconds"] > 0
     if name.startswith("r3"):   # round 3: executed-FLOP fraction, CPU baseline at physical-core thread counts, traffic only with a source stamp
