@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU session 2: the whole -m gpu suite (records gpurun_out/parity_values.json), then same-box A/B of the row-wise GroupNorm
+# (historical: PCDM_GN_ROWS selected the row-wise GroupNorm kernel, removed after this session -- profiles/r4_bench_gn_rows_ab.txt)
 # (PCDM_GN_ROWS=0) and of the CFG-shared prefix (PCDM_SHARE_CFG_PREFIX=0), GroupNorm micro-benchmark.   usage: bash tools/gpu_r4_s2.sh
 set -u
 OUT=gpurun_out/r4_s2

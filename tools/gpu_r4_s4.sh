@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU session 4: the software-pipelined self-attention kernel (flash_attn_pipe_kernel): parity tests, micro-benchmark A/B against
+# (historical: PCDM_ATTN_PIPE selected flash_attn_pipe_kernel, removed after this session -- profiles/r4_bench_attn_pipe_ab.txt)
 # the round-2 kernel (PCDM_ATTN_PIPE=0), end-to-end A/B.
 set -u
 OUT=gpurun_out/r4_s4

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU session 5: re-tune of the bench configuration's shapes on the round-4 kernels (incl. the dup_rows launches) + same-box A/B
+# (historical: PCDM_ATTN_LOWREG selected the four-workgroups-per-CU attention instance, removed after this session -- profiles/r4_bench_attn_lowreg_ab.txt)
 # against the committed table; the four-workgroups-per-CU attention instance (PCDM_ATTN_LOWREG=1) A/B.
 set -u
 OUT=gpurun_out/r4_s5
