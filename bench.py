@@ -346,12 +346,16 @@ def cpu_baseline(N, ddim_steps):
     pinned: ``OMP_PROC_BIND=close`` with explicit ``OMP_PLACES`` = one place per physical core, the cores of NUMA node 0
     first (then the following nodes) -- unpinned threads migrating across NUMA domains were why 64 threads measured slower than 32 in round 3.
       * ``value``: a BOUNDED sample of configs[1] -- one denoise step (UNet forward at the full latent size + CFG + DDIM update) for ONE
-        generated image (UNet batch 2), 1 warm-up + 2 timed steps per thread count (8 / 32 / 64 where the host has them), the best count
+        generated image (UNet batch 2), 1 warm-up + 2 timed steps per thread count (8 / 16 / 32 / 64 where the host has them, plus the container's cgroup CPU quota when it has one), the best count
         extrapolated to the 50-step call; images/s per process;
       * ``config1``: BASELINE.json configs[0] in FULL -- one 256x256 pair (latent 32x64), N = 1, 20 DDIM steps, guidance 2.0, fp32."""
     import subprocess
     topo = host_topology()
-    counts = sorted({c for c in (8, 32, 64) if c <= topo["physical_cores"]} | {min(8, topo["physical_cores"])})
+    counts = {c for c in (8, 16, 32, 64) if c <= topo["physical_cores"]} | {min(8, topo["physical_cores"])}
+    quota = topo.get("cgroup_cpu_quota_cores")
+    if quota:    # a CPU-bandwidth quota below the visible core count: threads beyond it only take turns (64 threads slower than 32 in round 3 / 4)
+        counts = {c for c in counts if c <= 2 * quota} | {max(1, min(int(quota), topo["physical_cores"]))}
+    counts = sorted(counts)
     # explicit places, one per physical core, NUMA node 0's cores first: thread i of the child's OpenMP team is bound to cpus[i], so a
     # run with n threads uses exactly the first n cores of that order (computed HERE: once OMP_PROC_BIND is in the environment the
     # child's own main thread is already bound to one CPU when it could look)
@@ -426,6 +430,24 @@ def cpu_baseline_worker():
     print(json.dumps({"host": topo, "per_thread_count": per,
                       "config1": {"workload": "configs[0]: 1 pair 256x256 (latent 32x64), N=1, 20 DDIM steps, guidance 2.0, fp32 CPU, full run",
                                   "threads": int(best), "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}), flush=True)
+
+
+def cgroup_cpu_quota():
+    """CPU-bandwidth quota of this container in cores (cgroup v2 ``cpu.max`` / v1 ``cpu.cfs_quota_us``), or None when unlimited / unreadable."""
+    try:
+        txt = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if txt and txt[0] != "max":
+            return round(int(txt[0]) / int(txt[1]), 2)
+        if txt:
+            return None
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        return round(q / per, 2) if q > 0 and per > 0 else None
+    except (OSError, ValueError):
+        return None
 
 
 def numa_nodes():
@@ -503,7 +525,8 @@ def host_topology():
     except AttributeError:
         avail = logical
     n_phys = max(1, min(n_phys, avail))
-    return {"sockets": n_sock, "physical_cores": n_phys, "cores_per_socket": max(1, n_phys // n_sock), "logical_cpus": logical}
+    return {"sockets": n_sock, "physical_cores": n_phys, "cores_per_socket": max(1, n_phys // n_sock), "logical_cpus": logical,
+            "cgroup_cpu_quota_cores": cgroup_cpu_quota()}
 
 
 if __name__ == "__main__":
