@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, GPU session 7: GroupNorm statistics from the producing GEMM (stats_out / pcdm_groupnorm_stats): kernel and schedule tests on
+# the GPU, producer -> norm pair timings, end-to-end A/B (PCDM_GN_PRODUCER_STATS=0/1 interleaved), full-size parity with the feature on.
+set -u
+REPO=$PWD
+OUT=$REPO/gpurun_out/r4_s7
+mkdir -p $OUT
+export TMPDIR=/tmp
+(timeout 600 python -m pytest tests/test_kernels.py tests/test_unet_ctx.py -q -m gpu -k "statistics" 2>&1 | tail -8) > $OUT/tests_stats.txt
+cat $OUT/tests_stats.txt
+(timeout 300 python tools/bench_gn_stats.py 2>&1 | grep -v amdgpu.ids) > $OUT/bench_gn_stats.txt
+cat $OUT/bench_gn_stats.txt
+B="--no-cpu-baseline --no-vae --no-roofline"
+for i in 1 2; do
+  for v in 0 1; do
+    (PCDM_GN_PRODUCER_STATS=$v timeout 300 python bench.py $B) > $OUT/bench_stats${v}_$i.json 2> $OUT/bench_stats${v}_$i.err
+    echo "stats=$v run $i: $(grep -o '"value": [0-9.]*' $OUT/bench_stats${v}_$i.json | head -1) $(grep -o '"ms_per_denoise_step": [0-9.]*' $OUT/bench_stats${v}_$i.json)"
+  done
+done
+(timeout 900 python -m pytest tests/test_fullsize_parity.py tests/test_pipeline.py tests/test_unet_ctx.py -q -m gpu 2>&1 | tail -8) > $OUT/tests_parity.txt
+cat $OUT/tests_parity.txt
