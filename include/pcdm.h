@@ -61,12 +61,6 @@ typedef struct pcdm_gn_splitk_src {
     void* pre_out;
     int32_t store_pre;
 } pcdm_gn_splitk_src;
-/* GroupNorm(+SiLU) of a tensor whose producer wrote the statistics (pcdm_gemm_params.stats_out of the pcdm_gemm launch that produced
- * x [B*HW, C]; prod_wn from pcdm_gemm_stats_geometry for its tile, prod_npad its Npad): one launch, one read and one write of the
- * tensor, no statistics pass and no exchange between workgroups.  HW % 32 == 0.  The statistics are those of the fp32 values in front
- * of x's bf16 rounding. */
-int pcdm_groupnorm_stats(const void* x, int C, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
-                         int fuse_silu, void* y, const float* stats, int prod_wn, int prod_npad, pcdm_stream_t s);
 int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* src, const void* x2, int C2, int B, int HW, int groups, float eps,
                           const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
 
@@ -146,25 +140,10 @@ typedef struct pcdm_gemm_params {
                               but its own time embedding -- the two classifier-free-guidance halves at conv_in and at the first ResnetBlock2D's
                               conv1 (stage2_inpaint_pipeline.py:499-501 doubles the latents; mask, masked latents and pose are shared).  Needs
                               N % 8 == 0, ldo % 8 == 0, rows_per_batch >= 32 and dup_rows % rows_per_batch == 0 with a rowvec; else -1 */
-    float* stats_out;      /* optional: the launch ALSO writes the GroupNorm statistics of `out` -- {sum, sum of squares} of the fp32 values in
-                              front of the bf16 rounding, per (block of 32 rows, column range of one wave of the tile, group of stats_gs
-                              channels) -- so that the GroupNorm which reads `out` next (ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm,
-                              conv_norm_out: every GroupNorm of the UNet reads a convolution's or a linear's output) is the
-                              normalise-and-write pass alone: pcdm_groupnorm_stats.  Layout and size: pcdm_gemm_stats_geometry.  The sums of
-                              a block do not depend on the tiling, so the norm of a sample does not depend on its position in the batch.
-                              Needs PCDM_EPI_STORE, act == 0, split_k <= 1, dup_rows == 0, N % 8 == 0, ldo % 8 == 0, M % 32 == 0,
-                              rows_per_batch % 32 == 0, M % rows_per_batch == 0, N % stats_gs == 0, stats_gs >= 8 (else -1) and a tile
-                              pcdm_gemm_stats_geometry accepts (else -4) */
-    int32_t stats_gs;      /* channels per group of that GroupNorm (N / its group count) */
 } pcdm_gemm_params;
-/* pcdm_version() == 3: the struct above ends with stats_out, stats_gs (2: ended with dup_rows; 1: with ln_eps).  Zero-initialise it (memset) and build against
+/* pcdm_version() == 2: the struct above ends with defer_reduce, rowvec_step, rowvec_step_stride, dup_rows (1: ended with ln_eps).  Zero-initialise it (memset) and build against
  * the header of the library in use: a host compiled against an older header passes a shorter struct. */
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
-/* The tiles that have an instance writing stats_out (0; -1 for the other tile ids): wn_out = the width of a wave's column range,
- * floats_out = the size of the statistics buffer for a launch of M rows and Npad padded columns with `groups` groups: the element of
- * (32-row block i, column range j, group g) is at ((i * (Npad / wn) + j) * groups + g) * 2 floats, (M / 32) * (Npad / wn) * groups * 2
- * floats in all; only the (j, g) pairs whose ranges intersect are written.  Any of the out pointers may be NULL. */
-int pcdm_gemm_stats_geometry(int tile, int M, int Npad, int groups, int* wn_out, int64_t* floats_out);
 
 /* ---- K9/K10 fused attention (replaces xformers.ops.memory_efficient_attention enabled at
  *      stage2_batchtest_inpaint_model.py:133).  head_dim = 64.  softmax(q k^T * scale) v, fp32 softmax.

@@ -75,14 +75,10 @@ __device__ __forceinline__ void lean_res_load(const GemmArgs& p, int lane, int m
 
 // RV: 0 = no row vector, 1 = row vector from the wave's LDS slice (rows b_lo and b_lo + 1 of it, staged before the first store), 2 = from
 // global memory per store instruction (wave tiles that span more than two batch entries: the 8x11 level)
-// ST: also take, per channel, the sum and the sum of squares of the 32 rows of this pass (the fp32 values in front of the bf16
-// rounding): each lane accumulates its 8 channels over its NIT rows, the row-lanes of a channel octet are reduced inside the wave
-// (pcdm_swap32 / pcdm_swap16 / DPP: no LDS atomics -- ds_add_f32 serialises its 64 lanes), and the pass's per-channel totals go to the
-// wave's LDS slice st_pass[stat * st_q + channel] with plain 16-byte stores.
-template <int WCOLS, int EPW, int RV, bool ST = false>
+template <int WCOLS, int EPW, int RV>
 __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, int lane, int mrow0, int ncol0, f32x4 b0, f32x4 b1,
                                           BufRsrc rs_o, BufRsrc rs_v, const u32x4 (&rv)[4], const float* rvec_w, int rv_pitch,
-                                          int rv_col0, int rv_split_row, float* st_pass = nullptr, int st_q = 0, bool st_on = false) {
+                                          int rv_col0, int rv_split_row) {
     typedef PassGeom<WCOLS> G;
     constexpr int LPR = G::LPR, RPI = G::RPI, NIT = G::NIT;
     constexpr bool TAIL = G::TAIL;
@@ -93,8 +89,7 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
     const uint32_t vo0 = lane_ok ? (uint32_t)(((mrow0 + rl) * (int)p.ldo + n) * 2) : kOOB;
     const uint32_t so = (uint32_t)(RPI * (int)p.ldo * 2);
     f32x4 t0[2], t1[2];
-    f32x4 ss0 = {0.f, 0.f, 0.f, 0.f}, ss1 = ss0, sq0 = ss0, sq1 = ss0;   // (ST) this lane's 8 channels over its NIT rows
-    if constexpr (RV == 1 && !ST) {   // the two candidate rows of the time-embedding projection, from LDS: no vector-memory load behind a store
+    if constexpr (RV == 1) {   // the two candidate rows of the time-embedding projection, from LDS: no vector-memory load behind a store
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             t0[h] = *(const f32x4*)(rvec_w + h * rv_pitch + rv_col0 + c8);
@@ -107,15 +102,10 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
         const int rr = (TAIL && r >= 32) ? 0 : r;
         const f32x4 v0 = *(const f32x4*)(ep + rr * EPW + c8), v1 = *(const f32x4*)(ep + rr * EPW + c8 + 4);
         f32x4 a0 = v0 + b0, a1 = v1 + b1;
-        if constexpr (RV == 1 && !ST) {
+        if constexpr (RV == 1) {
             const bool hi = mrow0 + r >= rv_split_row;   // first row of batch entry b_lo + 1
             a0 += hi ? t0[1] : t0[0];
             a1 += hi ? t1[1] : t1[0];
-        }
-        if constexpr (RV == 1 && ST) {   // (the statistics instance has no 16 registers for both candidate rows: the row is read per instruction)
-            const float* tp = rvec_w + (mrow0 + r >= rv_split_row ? rv_pitch : 0) + rv_col0 + c8;
-            a0 += *(const f32x4*)tp;
-            a1 += *(const f32x4*)(tp + 4);
         }
         if constexpr (RV == 2) {   // rows of one instruction span at most two batch entries (rows_per_batch >= 32 on this path)
             const int mb = mrow0 + it * RPI;                        // wave-uniform
@@ -136,50 +126,6 @@ __device__ __forceinline__ void lean_pass(const GemmArgs& p, const float* ep, in
         o[2] = pack2bf(a1[0], a1[1]);
         o[3] = pack2bf(a1[2], a1[3]);
         buf_store16(rs_o, (TAIL && r >= 32) ? kOOB : vo0 + it * so, o);
-        if constexpr (ST) {
-            if constexpr (TAIL || 64 % LPR != 0) {   // (48-channel passes only: idle lanes / rows beyond the pass count nothing)
-                const float w = (rl < RPI && r < 32) ? 1.f : 0.f;
-                a0 *= w;
-                a1 *= w;
-            }
-            ss0 += a0;
-            ss1 += a1;
-            sq0 += a0 * a0;
-            sq1 += a1 * a1;
-        }
-    }
-    if constexpr (ST && 64 % LPR == 0) {
-        if (st_on) {   // (wave-uniform: false for the passes of the last M tile that lie beyond M)
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = ss0[e];
-                v[4 + e] = ss1[e];
-                v[8 + e] = sq0[e];
-                v[12 + e] = sq1[e];
-            }
-            // lane = row-lane * LPR + octet: reduce over the row-lanes.  Lane bits 5 and 4 (row-lane bits for every LPR <= 8) by the
-            // transposing steps: afterwards lanes 0-31 hold sums, lanes 32-63 sums of squares; rows 0 / 2 of 16 lanes the octet's
-            // channels 0-3, rows 1 / 3 its channels 4-7
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pcdm_swap32(v[i], v[i + 8]);
-                v[i] += v[i + 8];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pcdm_swap16(v[i], v[i + 4]);
-                v[i] += v[i + 4];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {   // the row-lane bits below 16
-                if constexpr (LPR <= 8) v[i] += pcdm_row_ror<8>(v[i]);
-                if constexpr (LPR <= 4) v[i] += pcdm_row_ror<4>(v[i]);
-                if constexpr (LPR <= 2) v[i] += pcdm_row_ror<2>(v[i]);
-            }
-            const f32x4 tot = {v[0], v[1], v[2], v[3]};
-            *(f32x4*)(st_pass + ((lane >> 5) & 1) * st_q + c8 + ((lane >> 4) & 1) * 4) = tot;   // (the row-lanes of an octet store the same totals)
-        }
     }
 }
 
@@ -268,10 +214,7 @@ __device__ __forceinline__ void wait_lds_then_barrier() {  // this wave's ds_rea
 // 192x320 tile takes ~2.8 k cycles per K-tile whatever the problem (tools/gemm_anatomy.py), against 1.9 k cycles of MFMA issue: one
 // memory latency per K-tile, i.e. the ring is too shallow, not the matrix pipe too slow.  Loader ROLES: a DMA instruction covers
 // 16 rows of 64 bytes, so the (BM + BN) / 16 instructions of a tile are dealt out whole-operand -- waves [0, NWA) stage A, the rest B.
-// STATS: the instance that also emits GroupNorm statistics (pcdm_gemm_params.stats_out; p.stats is non-null, lean STORE epilogue,
-// split_k == 1, no dup_rows).  A separate instantiation: the per-channel accumulators of its passes would otherwise be part of every
-// launch's register allocation.
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32, int KB = 64, bool STATS = false>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32, int KB = 64>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int BK = KB;                 // (shadows the file-scope default of 64)
     constexpr int NW = WGM * WGN;
@@ -710,11 +653,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         const int rv_blo = wrow0 / p.rows_per_batch;
         const bool rv_lds = has_rv && (wrow0 + WM - 1) / p.rows_per_batch <= rv_blo + 1;
         const int rv_split_row = (rv_blo + 1) * p.rows_per_batch;
-        // GroupNorm statistics of the rows this launch writes (pcdm_gemm_params.stats_out): per wave [32-row block of the wave tile][sum |
-        // sum of squares][WNP channels] in LDS, filled pass by pass (lean_pass<ST>), folded per group by the wave itself after its last pass
-        constexpr int NJB_ST = WM / 32;
-        float* st_w = (float*)smem + NW * (32 * EPW) + NW * (3 * WNP) + wave * (NJB_ST * 2 * WNP);
-        constexpr bool do_stats = STATS && REP == 0;
         {
             if (REP) PCDM_WAVE_SYNC();   // (the first repetition's reads of the wave's LDS slices are done)
             if (lane * 4 < WN) {
@@ -840,19 +778,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
                 }
             } else {
                 const int rc0 = ncol0 - wcol0;
-                float* st_pass = st_w + jb * (2 * WNP) + rc0;
-#define PCDM_LEAN(W, RVK, ST_) lean_pass<W, EPW, RVK, ST_>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[RES ? q : 0], rvec_w, WNP, rc0, rv_split_row, st_pass, WNP, mrow0 < p.M)
-#define PCDM_LEAN_W(RVK, ST_)                 \
-    do {                                      \
-        if (wc == 64) PCDM_LEAN(64, RVK, ST_);      \
-        else if (wc == 32) PCDM_LEAN(32, RVK, ST_); \
-        else if (wc == 16) PCDM_LEAN(16, RVK, ST_); \
-        else PCDM_LEAN(48, RVK, ST_);               \
+#define PCDM_LEAN(W, RVK) lean_pass<W, EPW, RVK>(p, ep, lane, mrow0, ncol0, b0, b1, rs_o, rs_v, rv[RES ? q : 0], rvec_w, WNP, rc0, rv_split_row)
+#define PCDM_LEAN_W(RVK)                 \
+    do {                                 \
+        if (wc == 64) PCDM_LEAN(64, RVK);      \
+        else if (wc == 32) PCDM_LEAN(32, RVK); \
+        else if (wc == 16) PCDM_LEAN(16, RVK); \
+        else PCDM_LEAN(48, RVK);               \
     } while (0)
-                // (stats_out: M % 32 == 0, a pass is inside M as a whole; a pass beyond M contributes nothing)
-                if (!has_rv) PCDM_LEAN_W(0, do_stats);
-                else if (rv_lds) PCDM_LEAN_W(1, do_stats);
-                else PCDM_LEAN_W(2, do_stats);   // (never with STATS: BM <= rows_per_batch, a wave tile touches <= 2 batch entries)
+                if (!has_rv) PCDM_LEAN_W(0);
+                else if (rv_lds) PCDM_LEAN_W(1);
+                else PCDM_LEAN_W(2);
 #undef PCDM_LEAN_W
 #undef PCDM_LEAN
             }
@@ -861,31 +797,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs p) {
         };
         if (has_res) run_passes(std::true_type());
         else run_passes(std::false_type());
-        if constexpr (do_stats) {
-            // fold the per-channel totals into per-group totals and write them where the GroupNorm that follows looks for them:
-            // part[((blk * TW + wj) * G + g)][2], blk = the 32-row block (row / 32), wj = this wave's column range (column / WN), TW =
-            // Npad / WN.  32-row blocks never straddle batch entries (rows_per_batch % 32 == 0) and their sums do not depend on where
-            // the batch entry lies in the tiling: the norm stays independent of the position of a sample in the batch.  A group cut
-            // by a wave-column boundary has a partial in each of the two ranges.  One (block, group, statistic) per lane.
-            PCDM_WAVE_SYNC();
-            const int gs = p.stats_gs, G = p.N / gs, TW = p.Npad / WN;
-            const int c_end = wcol0 + WN < p.N ? wcol0 + WN : p.N;
-            const int g_first = wcol0 / gs, ng = c_end > wcol0 ? (c_end - 1) / gs - g_first + 1 : 0;
-            for (int item = lane; item < NJB_ST * ng * 2; item += 64) {
-                const int sq = item & 1, gl = (item >> 1) % ng, jb = (item >> 1) / ng;
-                const int mrow = wrow0 + jb * 32;
-                if (mrow >= p.M) continue;
-                const int g = g_first + gl;
-                const int c_lo = g * gs > wcol0 ? g * gs : wcol0, c_hi = (g + 1) * gs < c_end ? (g + 1) * gs : c_end;
-                const float* src = st_w + jb * (2 * WNP) + sq * WNP - wcol0;
-                float sum = 0.f;
-                for (int c = c_lo; c < c_hi; ++c) sum += src[c];
-                p.stats[((((int64_t)(mrow >> 5)) * TW + wcol0 / WN) * G + g) * 2 + sq] = sum;
-            }
-        }
         };   // epilogue_rep
         epilogue_rep(std::integral_constant<int, 0>());
-        if constexpr (CONV && !STATS) {   // (the second half of a dup_rows launch: its own output / residual / row-vector rows, the same accumulators)
+        if constexpr (CONV) {   // (the second half of a dup_rows launch: its own output / residual / row-vector rows, the same accumulators)
             if (p.dup_rows > 0) epilogue_rep(std::integral_constant<int, 1>());
         }
 #ifndef PCDM_EMU
@@ -1014,7 +928,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     *(u16x4*)((u16*)p.out + (int64_t)m * p.ldo + n) = o;
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32, int KB = 64, bool STATS = false>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, bool STAG = false, int F = 32, int KB = 64>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int BK = KB;
     // operand ring, or the wave-private fp32 epilogue tiles (32 x (WN + 4) floats per wave) if those need more
@@ -1022,14 +936,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int FN_ = BN / WGN / F, CGM_ = 64 / F;
     constexpr int WNP_ = (BN / WGN + 3) / 4 * 4;   // + per wave: bias slice and two row-vector rows (3 x WN floats)
     constexpr int smem_epi = WGM * WGN * (32 * ((FN_ < CGM_ ? FN_ : CGM_) * F + 4) + 3 * WNP_) * (int)sizeof(float);
-    constexpr int smem0 = smem_ops > smem_epi ? smem_ops : smem_epi;
-    // GroupNorm statistics (stats_out): [WM / 32][2][WNP] floats per wave behind the epilogue tiles
-    constexpr int smem_stats = smem_epi + WGM * WGN * (BM / WGM / 32) * 2 * WNP_ * (int)sizeof(float);
-    constexpr int smem = STATS && smem_stats > smem0 ? smem_stats : smem0;
-    if (STATS != (a.stats != nullptr)) return -4;
+    constexpr int smem = smem_ops > smem_epi ? smem_ops : smem_epi;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB, STATS>,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
@@ -1038,7 +948,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     GemmArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = a.Npad / BN;
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB, STATS>), dim3(g.tiles_m * g.tiles_n * g.split_k),
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, STAGES, CONV, STAG, F, KB>), dim3(g.tiles_m * g.tiles_n * g.split_k),
                 dim3(WGM * WGN * 64), smem, st, g);
     PCDM_CHECK_LAUNCH();
     if (g.split_k > 1 && !g.defer_reduce) {
@@ -1052,33 +962,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 // Tile configurations (id: BM x BN, waves, LDS stages -> LDS bytes, resident blocks per CU).
 // Which one wins depends on M, N, K and on how many workgroups the problem yields (measured: tools/bench_ops.py);
 // pcdms_amd.ops autotunes per problem shape at warm-up, id 0 = the static heuristic below.
-// the instances that emit GroupNorm statistics (stats_out): the tiles the tuner picks for the producers of level 0 / 1 (every one
-// of them fits the statistics slices into the LDS its operand ring already takes)
-template <bool CONV>
-int dispatch_tile_stats(int tile, const GemmArgs& a, hipStream_t st) {
-    switch (tile) {
-        case 1: return launch_gemm<256, 128, 4, 2, 3, CONV, false, 32, 64, true>(a, st);
-        case 4: return launch_gemm<128, 128, 2, 2, 2, CONV, false, 32, 64, true>(a, st);
-        case 5: return launch_gemm<128, 64, 2, 2, 2, CONV, false, 32, 64, true>(a, st);
-        case 10: return launch_gemm<128, 64, 2, 2, 3, CONV, false, 32, 64, true>(a, st);
-        case 11: return launch_gemm<256, 128, 4, 2, 3, CONV, true, 32, 64, true>(a, st);
-        case 18: return launch_gemm<128, 128, 4, 2, 2, CONV, false, 32, 64, true>(a, st);
-        case 21: return launch_gemm<192, 320, 2, 4, 2, CONV, false, 16, 64, true>(a, st);
-        default: return -4;
-    }
-}
-static int stats_tile_wn(int tile) {   // width of a wave's column range (the granularity of the statistics along N); 0: no instance
-    switch (tile) {
-        case 1: case 4: case 11: case 18: return 64;
-        case 5: case 10: return 32;
-        case 21: return 80;
-        default: return 0;
-    }
-}
-
 template <bool CONV>
 int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
-    if (a.stats) return dispatch_tile_stats<CONV>(tile, a, st);
     switch (tile) {
 #ifndef PCDM_DEV_NEW_TILES_ONLY   // (developer builds of a few instantiations: tools/ubench; never defined for the product)
         case 1: return launch_gemm<256, 128, 4, 2, 3, CONV>(a, st);   // 8 waves, 144 KiB, 1 block / CU
@@ -1183,14 +1068,6 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         if (p->rowvec && (p->rows_per_batch < 32 || a.dup_rows % p->rows_per_batch)) return -1;
         if (((int64_t)p->M + a.dup_rows) * (p->ldo > 0 ? p->ldo : p->N) * 2 >= lim) return -2;
     }
-    a.stats = p->stats_out;
-    a.stats_gs = p->stats_gs;
-    if (a.stats) {   // (the lean STORE epilogue, whole 32-row passes inside one batch entry)
-        if (p->epilogue != PCDM_EPI_STORE || p->act || p->split_k > 1 || p->dup_rows || (p->N & 7) || (p->ldo & 7) || p->M % 32 ||
-            p->rows_per_batch % 32 || p->M % p->rows_per_batch || p->stats_gs < 8 || p->N % p->stats_gs)
-            return -1;
-        if (p->residual && ((p->ldr & 7) || (p->res_mod > 0 && p->res_mod < p->M))) return -1;
-    }
     a.zero_rows = p->zero_rows;
     if (a.zero_rows < 0 || a.zero_rows > p->M || (a.zero_rows && p->conv)) return -1;
     if (a.act < 0 || a.act > PCDM_ACT_GELU || (a.act == PCDM_ACT_GELU && p->epilogue == PCDM_EPI_GEGLU)) return -1;
@@ -1215,7 +1092,6 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (p->epilogue == PCDM_EPI_SPLIT_VT && (!p->out2 || p->vt_col0 % 4)) return -1;
     hipStream_t st = (hipStream_t)s;
     int tile = p->tile & 0xff;
-    if (tile >= pcdm_gemm_detail::kRowGemmTile0 && a.stats) return -4;
     if (tile >= pcdm_gemm_detail::kRowGemmTile0) {
         if ((a.debug & 4) && p->ws_floats < (int64_t)((p->M + 95) / 96) * 8 * 8 * 2) return -1;   // (stamps: 8 x uint64 per wave)
         return p->conv ? -1 : pcdm_gemm_detail::launch_rowgemm(tile, a, st);
@@ -1235,15 +1111,4 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         return -1;
     }
     return p->conv ? dispatch_tile<true>(tile, a, st) : dispatch_tile<false>(tile, a, st);
-}
-
-extern "C" int pcdm_gemm_stats_geometry(int tile, int M, int Npad, int groups, int* wn_out, int64_t* floats_out) {
-    const int wn = stats_tile_wn(tile & 0xff);
-    if (!wn) return -1;
-    if (wn_out) *wn_out = wn;
-    if (floats_out) {
-        if (M <= 0 || M % 32 || Npad <= 0 || Npad % wn || groups <= 0) return -1;
-        *floats_out = (int64_t)(M / 32) * (Npad / wn) * groups * 2;
-    }
-    return 0;
 }

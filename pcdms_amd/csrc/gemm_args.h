@@ -39,8 +39,6 @@ struct GemmArgs {
     float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
     int dup_rows;       // conv, lean epilogue: also write rows m + dup_rows (their own rowvec / residual rows): pcdm_gemm_params.dup_rows
     int defer_reduce;   // split_k > 1: no reduce launch (pcdm_groupnorm_splitk consumes the partial slabs)
-    float* stats;       // lean STORE epilogue, split_k == 1: per-(batch, M-tile, N-tile, group) {sum, sum of squares} of the rows this workgroup
-    int stats_gs;       // writes (pcdm_gemm_params.stats_out: the GroupNorm that reads `out` next needs no statistics pass); channels per group
     int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
                 // phase time stamps (s_memtime) into ws[wg][8] as uint64 (tools/gemm_anatomy.py)
 };

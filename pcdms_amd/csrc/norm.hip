@@ -192,23 +192,13 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restric
     }
 }
 
-// Where the partial sums come from when the tensor's PRODUCER wrote them (pcdm_gemm_params.stats_out, gemm.hip): one
-// {sum, sum of squares} per (32-row block, wave-column range of wn channels, group) at part[((blk * tw + j) * groups + g)][2], blk =
-// row / 32, j = channel / wn.  wn == 0: gn_stats_kernel's [B][nchunk][groups][2].
-struct GnProd {
-    int wn, tw;
-};
-struct GnPair {   // {sum, sum of squares}
-    float x, y;
-};
-
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restrict__ x1, int C1,
                                                           const u16* __restrict__ x2, int C2, int HW,
                                                           int rows_per_chunk, int groups, float eps,
                                                           const float* __restrict__ part,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int fuse_silu,
-                                                          u16* __restrict__ y, const GnProd prod) {
+                                                          u16* __restrict__ y) {
     __shared__ float stat[2 * 256];  // {mean, rstd} per group of this batch row
     const int C = C1 + C2;
     const GnGeom g = gn_geom(C);
@@ -226,29 +216,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
         const int nsub = kThreads / groups > 0 ? kThreads / groups : 1;   // groups <= 256
         const int sub = t / groups, grp = t - sub * groups;
         double s = 0.0, q = 0.0;
-        if (sub < nsub && prod.wn > 0) {   // the producer's 32-row blocks of batch entry b x the wave-column ranges that touch group grp
-            const int blk0 = (int)(((int64_t)b * HW) >> 5), nblk = HW >> 5;
-            const int j_lo = (grp * gs) / prod.wn, j_hi = ((grp + 1) * gs - 1) / prod.wn;
-            const GnPair* pp = (const GnPair*)part + ((int64_t)blk0 * prod.tw + j_lo) * groups + grp;
-            const int64_t bstep = (int64_t)prod.tw * groups;
-            // eight blocks' partials in flight per thread (the loads are independent; a serial chain of L2 round trips per block would
-            // cost more than the streaming pass), summed in block order
-            for (int i0 = sub; i0 < nblk; i0 += 8 * nsub) {
-                GnPair v0[8], v1[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * nsub;
-                    const GnPair z = {0.f, 0.f};
-                    v0[u] = i < nblk ? pp[i * bstep] : z;
-                    v1[u] = (i < nblk && j_hi > j_lo) ? pp[i * bstep + groups] : z;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    s += (double)v0[u].x + (double)v1[u].x;
-                    q += (double)v0[u].y + (double)v1[u].y;
-                }
-            }
-        } else if (sub < nsub) {
+        if (sub < nsub) {
             for (int ch = sub; ch < nchunk; ch += nsub) {
                 const float* ps = part + (((int64_t)b * nchunk + ch) * groups + grp) * 2;
                 s += (double)ps[0];
@@ -920,7 +888,7 @@ static int gn_launch(GnSrc src, int B, int HW, int groups, float eps, const floa
     PCDM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, src.x1, C1, src.x2, C2, HW, rpc, groups, ws);
     PCDM_CHECK_LAUNCH();
     PCDM_LAUNCH(gn_apply_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, src.x1, C1, src.x2, C2, HW, rpc, groups, eps, (const float*)ws, gamma,
-                beta, fuse_silu, (u16*)y, GnProd{0, 0});
+                beta, fuse_silu, (u16*)y);
     PCDM_CHECK_LAUNCH();
     return 0;
 }
@@ -934,23 +902,6 @@ extern "C" int pcdm_groupnorm(const void* x1, int C1, const void* x2, int C2, in
     GnSrc src{};
     src.x1 = (const u16*)x1; src.C1 = C1; src.x2 = (const u16*)x2; src.C2 = C2;
     return gn_launch(src, B, HW, groups, eps, gamma, beta, fuse_silu, y, ws, (hipStream_t)s);
-}
-
-// GroupNorm of a tensor whose producer already wrote the statistics (pcdm_gemm_params.stats_out): the normalise-and-write pass alone
-extern "C" int pcdm_groupnorm_stats(const void* x, int C, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
-                                    int fuse_silu, void* y, const float* stats, int prod_wn, int prod_npad, pcdm_stream_t s) {
-    if (!x || !y || !stats || B <= 0 || HW <= 0 || groups <= 0 || groups > 256) return -1;
-    if (C <= 0 || C % 8 || C % groups || C > kGnMaxC || C / groups < 8) return -1;
-    if (prod_wn <= 0 || prod_npad < C || prod_npad % prod_wn || HW % 32 || C / groups > prod_wn) return -1;   // (a group lies in <= 2 column ranges)
-    const GnGeom g = gn_geom(C);
-    const int nchunk = gn_chunks(HW, g.rows_par);
-    const int rpc = (HW + nchunk - 1) / nchunk;
-    const GnProd prod{prod_wn, prod_npad / prod_wn};
-    hipStream_t st = (hipStream_t)s;
-    PCDM_LAUNCH(gn_apply_kernel, dim3(nchunk, B), dim3(kThreads), 0, st, (const u16*)x, C, (const u16*)nullptr, 0, HW, rpc, groups, eps, stats,
-                gamma, beta, fuse_silu, (u16*)y, prod);
-    PCDM_CHECK_LAUNCH();
-    return 0;
 }
 
 extern "C" int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* p, const void* x2, int C2, int B, int HW, int groups, float eps,

@@ -323,39 +323,6 @@ __device__ __forceinline__ f32x16 mfma_f8_32x32x64(u32x8 a, u32x8 b, f32x16 c) {
 #endif
 }
 
-// Cross-lane pieces of a "transposing" wave reduction (gemm.hip: GroupNorm statistics in the epilogue): with two values per lane,
-// swap + add leaves the lower half of the lanes with the first value summed over lanes l, l ^ 32 and the upper half with the second
-// (v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b); the same over l, l ^ 16 by rows of 16 lanes (v_permlane16_swap: odd rows
-// of a <-> even rows of b); and x + x[l ^ n] inside a row of 16 for values that are already n-periodic there (DPP row_ror:n).
-#ifdef PCDM_EMU
-__device__ __forceinline__ void pcdm_swap32(float& a, float& b) {
-    const int lane = threadIdx.x & 63;
-    const float ax = __shfl_xor(a, 32), bx = __shfl_xor(b, 32);
-    if (lane & 32) a = bx; else b = ax;
-}
-__device__ __forceinline__ void pcdm_swap16(float& a, float& b) {
-    const int lane = threadIdx.x & 63;
-    const float ax = __shfl_xor(a, 16), bx = __shfl_xor(b, 16);
-    if (lane & 16) a = bx; else b = ax;
-}
-template <int N>
-__device__ __forceinline__ float pcdm_row_ror(float x) { return __shfl_xor(x, N); }   // (only ever added to an N-periodic x: the same sum)
-#else
-// (inline asm, not __builtin_amdgcn_permlane32_swap / 16_swap: hipcc 7.2 folded "a' + b'" of the builtin's two results into "a' + a'" in
-//  gemm.hip's reduction -- tools/debug_stats.py found the sums of 8 row-lanes to be 4 x the first two.  s_nop 1 on both sides: the
-//  hazard recognizer does not see into the asm; the swap reads VGPRs a VALU instruction may just have written, and is read right after)
-__device__ __forceinline__ void pcdm_swap32(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void pcdm_swap16(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-template <int N>
-__device__ __forceinline__ float pcdm_row_ror(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, x), 0x120 + N, 0xf, 0xf, false));
-}
-#endif
-
 // ---- inter-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16) ----------------
 #ifdef PCDM_EMU
 __device__ __forceinline__ void pcdm_drain_vmem() {}

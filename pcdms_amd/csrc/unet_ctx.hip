@@ -64,11 +64,6 @@ struct pcdm_unet {
 namespace {
 constexpr int64_t kAlign = 256;
 constexpr int64_t kSplitKFloats = 1 << 24;   // split-K workspace (fp32), as pcdms_amd.ops._splitk_ws
-constexpr int64_t kGnStatsFloats = 1 << 20;  // GroupNorm statistics written by a producing GEMM (pcdm_gemm_params.stats_out)
-int gn_stats_min_hw() {                      // as pcdms_amd.ops.STATS_MIN_HW (PCDM_GN_STATS_MIN_HW: tests run the path on small feature maps)
-    const char* e = getenv("PCDM_GN_STATS_MIN_HW");
-    return e && *e ? atoi(e) : 1024;
-}
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 bool getenv_off(const char* name) {   // A/B switches shared with pcdms_amd.ops ("0" = off)
@@ -191,13 +186,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride
         int64_t rowvec_step_stride = 0;
         int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
-        int gn_stats = 0;   // 1: `out` is read next by a single-input GroupNorm: write its statistics from the epilogue where the tile in use can
     };
-    // the GEMM that wrote the statistics of its output (pcdm_gemm_params.stats_out): used by the next groupnorm() if that reads exactly `out`
-    struct {
-        const void* out = nullptr;
-        int N = 0, rpb = 0, wn = 0, npad = 0;
-    } stats;
     // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
     pcdm_gn_splitk_src pend;
     const void* pend_out = nullptr;
@@ -258,19 +247,6 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
             pend.pre_out = out; pend.store_pre = g.defer == 1;
             pend_out = out;
         }
-        stats.out = nullptr;
-        if (g.gn_stats && p.split_k <= 1 && !getenv_off("PCDM_GN_PRODUCER_STATS")) {
-            const int rpb = p.rows_per_batch, groups = u->cfg.norm_groups;
-            int wn = 0;
-            int64_t nfl = 0;
-            if (g.epilogue == PCDM_EPI_STORE && !g.dup_rows && rpb >= gn_stats_min_hw() && M % 32 == 0 && rpb % 32 == 0 && M % rpb == 0 && w->N % 8 == 0 &&
-                w->N % groups == 0 && w->N / groups >= 8 && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0) &&
-                pcdm_gemm_stats_geometry(p.tile, M, w->Npad, groups, &wn, &nfl) == 0 && nfl <= kGnStatsFloats && w->N / groups <= wn) {
-                p.stats_out = buf<float>("gnstats");
-                p.stats_gs = w->N / groups;
-                stats.out = out; stats.N = w->N; stats.rpb = rpb; stats.wn = wn; stats.npad = w->Npad;
-            }
-        }
         chk(pcdm_gemm(&p, st), "pcdm_gemm");
     }
     // LayerNorm -> GEMM: the folded form on the A-in-registers kernel when the table says so, two launches otherwise
@@ -306,13 +282,6 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
             chk(pcdm_groupnorm_splitk(&pend, x2, C2, B, HW, u->cfg.norm_groups, eps, gamma, beta, silu, y, buf<float>("gnws"), st), "pcdm_groupnorm_splitk");
             return;
         }
-        if (stats.out && stats.out == x1 && !x2 && stats.N == C1 && stats.rpb == HW) {
-            stats.out = nullptr;
-            chk(pcdm_groupnorm_stats(x1, C1, B, HW, u->cfg.norm_groups, eps, gamma, beta, silu, y, buf<float>("gnstats"), stats.wn, stats.npad, st),
-                "pcdm_groupnorm_stats");
-            return;
-        }
-        stats.out = nullptr;
         chk(pcdm_groupnorm(x1, C1, x2, C2, B, HW, u->cfg.norm_groups, eps, gamma, beta, silu, y, buf<float>("gnws"), st), "pcdm_groupnorm");
     }
 };
@@ -353,7 +322,6 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
     // ---- conditioning (step-invariant)
     P.add("gnws", pcdm_groupnorm_ws_floats(B, 4096) * 4);
     P.add("splitk", kSplitKFloats * 4);
-    P.add("gnstats", kGnStatsFloats * 4);
     P.add("cls1", (int64_t)B * temb_dim * 4);
     P.add("cls2", (int64_t)B * temb_dim * 4);
     P.add("pose", M0 * C0 * 2);
@@ -675,7 +643,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         R.groupnorm(x1, C1, nullptr, 0, Bs, HW_, e, gamma, beta, 1, R.buf("gn"));
     };
     auto resnet = [&](const std::string& p, const void* x1, int C1, const void* x2, int C2, int HW_, int hh, int ww, const std::string& out_name,
-                      bool gn_next, bool shared_in = false, bool gn_single = false) -> void* {   // gn_next: the next reader of the block's output is a GroupNorm (split-K reduce folded into it); gn_single: ... a single-input one (statistics from conv2's epilogue)
+                      bool gn_next, bool shared_in = false) -> void* {   // gn_next: the next reader of the block's output is a GroupNorm (split-K reduce folded into it)
         const PW *cv1 = R.pw(p + "conv1"), *cv2 = R.pw(p + "conv2");
         if (R.rc) return nullptr;
         const int cin = C1 + C2, cout = cv1->N, M = B * HW_;
@@ -691,7 +659,6 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         } else {
             R.groupnorm(x1, C1, x2, C2, B, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"), 1, R.buf("gn"));
             g.defer = 2;
-            g.gn_stats = 1;   // -> norm2
             R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
         }
         R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
@@ -706,14 +673,12 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         g2.conv = 1; g2.B = B; g2.Hi = hh; g2.Wi = ww; g2.Ho = hh; g2.Wo = ww;
         g2.residual = res; g2.ldr = cout; g2.res_mod = M;
         g2.defer = gn_next ? 1 : 0;
-        g2.gn_stats = gn_single ? 1 : 0;
-        g2.rows_per_batch = HW_;
         void* out = R.buf(out_name);
         R.gemm(R.buf("gn"), cout, M, cv2, out, g2);
         return out;
     };
 
-    auto transformer = [&](const std::string& p, const void* x, int cc, int H, int HW_, const std::string& out_name, bool gn_single = false) -> void* {
+    auto transformer = [&](const std::string& p, const void* x, int cc, int H, int HW_, const std::string& out_name) -> void* {
         const int M = B * HW_;
         const std::string b = p + "transformer_blocks.0.";
         R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"));
@@ -773,8 +738,6 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         }
         Run::G g;
         g.residual = x; g.ldr = cc; g.res_mod = M;
-        g.gn_stats = gn_single ? 1 : 0;
-        g.rows_per_batch = HW_;
         void* out = R.buf(out_name);
         R.gemm(R.buf("t1"), cc, M, R.pw(p + "proj_out"), out, g);
         return out;
@@ -805,12 +768,11 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         int cprev = i == 0 ? C0 : c.block_out_channels[i - 1];
         for (int j = 0; j < Lb; ++j) {
             const std::string nm = "d" + std::to_string(i) + "." + std::to_string(j), rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".";
-            const bool to_norm1 = j < Lb - 1 || i == n - 1;   // the next reader is a resnet's norm1 (same block, or the mid block), not a downsampling conv
             if (has_cross(c, i)) {
-                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r", true, shared && i == 0 && j == 0, true);
-                x = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, ci, c.heads[i], hh * ww, nm, to_norm1);
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, "r", true, shared && i == 0 && j == 0);
+                x = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, ci, c.heads[i], hh * ww, nm);
             } else {
-                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm, to_norm1, shared && i == 0 && j == 0, to_norm1);
+                x = resnet(rp, x, j == 0 ? cprev : ci, nullptr, 0, hh * ww, hh, ww, nm, j < Lb - 1 || i == n - 1, shared && i == 0 && j == 0);
             }
             skips.push_back({x, hh, ww, ci});
         }
@@ -819,7 +781,6 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             Run::G g;
             g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = ho; g.Wo = wo; g.stride = 2;
             g.defer = 1;   // -> the next block's norm1
-            g.gn_stats = 1; g.rows_per_batch = ho * wo;
             void* o = R.buf("ds" + std::to_string(i));
             R.gemm(x, 0, B * ho * wo, R.pw("down_blocks." + std::to_string(i) + ".downsamplers.0.conv"), o, g);
             x = o;
@@ -829,9 +790,9 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     }
     // ---- 4. mid (ref :775-783)
     const int cm = c.block_out_channels[n - 1];
-    x = resnet("mid_block.resnets.0.", x, cm, nullptr, 0, hh * ww, hh, ww, "r", true, false, true);
-    x = transformer("mid_block.attentions.0.", x, cm, c.heads[n - 1], hh * ww, "r2", true);
-    x = resnet("mid_block.resnets.1.", x, cm, nullptr, 0, hh * ww, hh, ww, "r", true);   // (-> the first up resnet's norm1: a concat)
+    x = resnet("mid_block.resnets.0.", x, cm, nullptr, 0, hh * ww, hh, ww, "r", true);
+    x = transformer("mid_block.attentions.0.", x, cm, c.heads[n - 1], hh * ww, "r2");
+    x = resnet("mid_block.resnets.1.", x, cm, nullptr, 0, hh * ww, hh, ww, "r", true);
     // ---- 5. up (ref :789-814)
     int cx = cm;
     for (int i = 0; i < n && !R.rc; ++i) {
@@ -840,12 +801,11 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             const Skip sk = skips.back();
             skips.pop_back();
             if (sk.hh != hh || sk.ww != ww) { u->err = "skip size mismatch"; return -1; }
-            const bool last = i == n - 1 && j == Lb;   // -> conv_norm_out (single input; every other norm1 of the up path reads a concat)
             x = resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", x, cx, sk.p, sk.ch, hh * ww, hh, ww, (j + i) % 2 ? "r" : "rb",
-                       has_cross(c, n - 1 - i) || j < Lb || i == n - 1, false, has_cross(c, n - 1 - i) || last);
+                       has_cross(c, n - 1 - i) || j < Lb || i == n - 1);
             cx = co;
             if (has_cross(c, n - 1 - i))
-                x = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, co, c.heads[n - 1 - i], hh * ww, j % 2 ? "u" : "ub", last);
+                x = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", x, co, c.heads[n - 1 - i], hh * ww, j % 2 ? "u" : "ub");
         }
         if (i != n - 1) {
             const int ho = skips.back().hh, wo = skips.back().ww;   // = (2 hh, 2 ww) unless a down conv rounded an odd size up

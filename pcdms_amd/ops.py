@@ -25,11 +25,6 @@ BF16 = torch.bfloat16
 LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
 AUTOTUNE = True                    # pick the GEMM tile configuration per problem shape at first use (GPU only)
 DEFER_SPLITK = os.environ.get("PCDM_DEFER_SPLITK", "1") != "0"   # split-K reduce folded into the consuming GroupNorm (A/B switch)
-PRODUCER_STATS = os.environ.get("PCDM_GN_PRODUCER_STATS", "1") != "0"   # GroupNorm statistics written by the producing GEMM's epilogue (A/B switch)
-# rows per batch entry from which the statistics-free GroupNorm pays (below: one workgroup holds the slab in registers); the C schedule
-# (csrc/unet_ctx.hip) reads the same variable
-STATS_MIN_HW = int(os.environ.get("PCDM_GN_STATS_MIN_HW") or 1024)
-STATS_TILES = {1: 64, 4: 64, 5: 32, 10: 32, 11: 64, 18: 64, 21: 80}   # tile -> width of a wave's column range (pcdm_gemm_stats_geometry)
 
 
 def _stream(t: torch.Tensor) -> Optional[int]:
@@ -91,38 +86,8 @@ class DeferredGemm:
         return self.out
 
 
-class StatsGemm:
-    """What ``gemm(..., gn_stats=groups)`` returns when the launch also wrote the GroupNorm statistics of its output
-    (``pcdm_gemm_params.stats_out``): ``out`` IS written; the single-input ``groupnorm`` that takes this object runs the
-    normalise-and-write pass alone (``pcdm_groupnorm_stats``).  Any other consumer uses ``out`` (``as_tensor``)."""
-
-    __slots__ = ("out", "stats", "wn", "npad", "groups", "rpb")
-
-    def __init__(self, **kw):
-        for k, v in kw.items():
-            setattr(self, k, v)
-
-    @property
-    def shape(self):
-        return self.out.shape
-
-    def tensor(self) -> torch.Tensor:
-        return self.out
-
-
-def as_tensor(x: Union[torch.Tensor, "DeferredGemm", "StatsGemm"]) -> torch.Tensor:
-    return x.tensor() if isinstance(x, (DeferredGemm, StatsGemm)) else x
-
-
-_stats_bufs: dict = {}
-
-
-def _stats_buf(device, n: int) -> torch.Tensor:
-    """fp32 statistics buffer (one per device and size: a producer's statistics are consumed by the very next GroupNorm)."""
-    key = (str(device), n)
-    if key not in _stats_bufs:
-        _stats_bufs[key] = torch.empty(n, dtype=torch.float32, device=device)
-    return _stats_bufs[key]
+def as_tensor(x: Union[torch.Tensor, "DeferredGemm"]) -> torch.Tensor:
+    return x.tensor() if isinstance(x, DeferredGemm) else x
 
 
 def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
@@ -136,15 +101,7 @@ def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor
     if log:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if isinstance(x1, StatsGemm) and not (x2 is None and x1.groups == groups and x1.rpb == HW and x1.out.shape == (B * HW, C1)):
-        x1 = x1.out   # (a concat / another grouping: the statistics do not apply)
-    if isinstance(x1, StatsGemm):
-        sg = x1
-        x1 = _c(sg.out, BF16)
-        rc = _lib.lib().pcdm_groupnorm_stats(_ptr(x1), C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta), int(silu), _ptr(out), _ptr(sg.stats),
-                                            sg.wn, sg.npad, _stream(out))
-        _chk(rc, "pcdm_groupnorm_stats")
-    elif isinstance(x1, DeferredGemm):
+    if isinstance(x1, DeferredGemm):
         d = x1
         assert d.M == B * HW and d.N == C1 and (d.rowvec is None or d.rpb == HW), "rowvec rows must be the GroupNorm's batch entries"
         sp = _lib.GnSplitKSrc()
@@ -278,7 +235,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
          defer_reduce: Optional[bool] = None, dup_rows: int = 0, rowvec_step: Optional[torch.Tensor] = None,
-         rowvec_step_stride: int = 0, gn_stats: Optional[int] = None) -> Union[torch.Tensor, "DeferredGemm", "StatsGemm"]:
+         rowvec_step_stride: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
@@ -294,9 +251,6 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
 
     ``rowvec_step`` (device int32 counter) / ``rowvec_step_stride`` (floats): the row-vector block in use is ``rowvec + *rowvec_step *
     rowvec_step_stride`` -- the per-step slice of a table that holds the time-embedding projections of every denoise step.
-
-    ``gn_stats`` (= the group count of the GroupNorm that reads ``out`` next, as a single input): when the configuration in use does
-    not split K and its tile can (``STATS_TILES``), the launch also writes that GroupNorm's statistics and a ``StatsGemm`` is returned.
 
     ``dup_rows`` (conv only): ``out`` has ``M + dup_rows`` rows; rows ``m + dup_rows`` get the same contraction with THEIR row-vector /
     residual rows (``pcdm_gemm_params.dup_rows``: the CFG-shared prefix of the UNet)."""
@@ -375,16 +329,6 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
                                     ldrv=p.ldrv if rowvec is not None else 0, rowvec_step=p.rowvec_step, rowvec_step_stride=p.rowvec_step_stride,
                                     rpb=p.rows_per_batch, residual=p.residual, ldr=p.ldr, out=out,
                                     store=bool(defer_reduce), keep=(ws, rowvec, residual, pw, rowvec_step))
-    stats = None
-    rpb_ = p.rows_per_batch
-    if (gn_stats and PRODUCER_STATS and split == 1 and tile in STATS_TILES and epilogue == EPI_STORE and act == ACT_NONE and not dup_rows
-            and rpb_ >= STATS_MIN_HW and M % 32 == 0 and rpb_ % 32 == 0 and M % rpb_ == 0
-            and pw.N % 8 == 0 and pw.N % gn_stats == 0 and 8 <= pw.N // gn_stats <= STATS_TILES[tile] and pw.Npad % STATS_TILES[tile] == 0
-            and (residual is None or res_mod in (0, M)) and out.dim() == 2 and out.shape == (M, pw.N) and out.stride(0) % 8 == 0):
-        wn = STATS_TILES[tile]
-        sbuf = _stats_buf(a.device, (M // 32) * (pw.Npad // wn) * gn_stats * 2)
-        p.stats_out, p.stats_gs = sbuf.data_ptr(), pw.N // gn_stats
-        stats = StatsGemm(out=out, stats=sbuf, wn=wn, npad=pw.Npad, groups=gn_stats, rpb=rpb_)
     if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -394,9 +338,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         # field is what the launch executes
         LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split),
                            2.0 * (M - zero_rows) * pw.alg_nk))
-        return stats if stats is not None else (out if deferred is None else deferred)
+        return out if deferred is None else deferred
     _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
-    return stats if stats is not None else (out if deferred is None else deferred)
+    return out if deferred is None else deferred
 
 
 def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile):

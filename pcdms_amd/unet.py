@@ -617,11 +617,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         # loads its slab (ops.DeferredGemm / pcdm_groupnorm_splitk): no reduce launch, no bf16 round trip in front of the norm.  The bf16
         # tensor itself is written by that norm where a residual, shortcut or skip connection reads it later (`gn_next`: the caller
         # knows whether the next consumer of the block's output is a GroupNorm).
-        # GEMMs that do not split K and whose output goes into a single-input GroupNorm next (`gn_single`: conv1 -> norm2 always; a
-        # block's output -> the transformer's norm / the next resnet's norm1 of the down and mid path / conv_norm_out) also write that
-        # norm's statistics from their epilogue (ops.StatsGemm / pcdm_groupnorm_stats) where the feature map is large enough for the
-        # norm to be a multi-workgroup launch (levels 0 and 1): the norm is then the normalise-and-write pass alone.
-        def resnet(p, x1, x2, HW_, hh, ww, name, gn_next=False, shared=False, gn_single=False):
+        def resnet(p, x1, x2, HW_, hh, ww, name, gn_next=False, shared=False):
             r = W[p]
             cin, cout, M = r["cin"], r["cout"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
@@ -637,16 +633,16 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
                 cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
                 h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False,
-                              rowvec_step=rv_step, rowvec_step_stride=rv_stride, gn_stats=G)
+                              rowvec_step=rv_step, rowvec_step_stride=rv_stride)
             n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
             else:
                 res = x1
-            return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M, rows_per_batch=HW_,
-                            defer_reduce=True if gn_next else None, gn_stats=G if gn_single else None)
+            return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M,
+                            defer_reduce=True if gn_next else None)
 
-        def transformer(p, x, HW_, name, gn_single=False):
+        def transformer(p, x, HW_, name):
             a = W[p]
             c, H, M = a["c"], a["heads"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
@@ -682,8 +678,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             ff = ops.gemm(t2, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU, ln=(a["ln3"][0], a["ln3"][1], 1e-5),
                           ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("ff1_ln"))
             t3 = ops.gemm(ff, a["ff2"], self._buf("t1", (M, c)), residual=t2, res_mod=M)
-            return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M, rows_per_batch=HW_,
-                            gn_stats=G if gn_single else None)
+            return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M)
 
         # ---- 2. conv_in + pose (ref :742)
         HW = h * w
@@ -703,29 +698,28 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         L_ = self._layers[0]
 
         def skip_of(t):   # (a deferred tensor's buffer: filled by the norm that follows, long before the up path reads it)
-            return t.out if isinstance(t, (ops.DeferredGemm, ops.StatsGemm)) else t
+            return t.out if isinstance(t, ops.DeferredGemm) else t
         for i, typ in enumerate(cfg.down_block_types):
             for j in range(L_):
                 nm = f"d{i}.{j}"
                 first = shared and i == 0 and j == 0
-                to_norm1 = j < L_ - 1 or i == nlev - 1   # the next consumer is a resnet's norm1 (same block, or the mid block), not a downsampling conv
                 if typ == "CrossAttnDownBlock2D":
-                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r", gn_next=True, shared=first, gn_single=True)
-                    x = transformer(f"down_blocks.{i}.attentions.{j}.", x, hh * ww, nm, gn_single=to_norm1)
-                else:
-                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm, gn_next=to_norm1, shared=first, gn_single=to_norm1)
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, "r", gn_next=True, shared=first)
+                    x = transformer(f"down_blocks.{i}.attentions.{j}.", x, hh * ww, nm)
+                else:   # the next consumer is a resnet's norm1 (same block, or the mid block) unless a downsampling conv follows
+                    x = resnet(f"down_blocks.{i}.resnets.{j}.", x, None, hh * ww, hh, ww, nm, gn_next=j < L_ - 1 or i == nlev - 1, shared=first)
                 skips.append((skip_of(x), hh, ww))
             if i != nlev - 1:
                 ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
-                x = ops.gemm(ops.as_tensor(x).view(B, hh, ww, boc[i]), W[f"down_blocks.{i}.downsamplers.0.conv."],
-                             self._buf(f"ds{i}", (B * ho * wo, boc[i])), rows_per_batch=ho * wo,
-                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, stride=2), defer_reduce=True, gn_stats=G)   # -> the next block's norm1
+                x = ops.gemm(x.view(B, hh, ww, boc[i]), W[f"down_blocks.{i}.downsamplers.0.conv."],
+                             self._buf(f"ds{i}", (B * ho * wo, boc[i])),
+                             conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, stride=2), defer_reduce=True)   # -> the next block's norm1
                 hh, ww = ho, wo
                 skips.append((skip_of(x), hh, ww))
         # ---- 4. mid (ref :775-783)
-        x = resnet("mid_block.resnets.0.", x, None, hh * ww, hh, ww, "r", gn_next=True, gn_single=True)
-        x = transformer("mid_block.attentions.0.", x, hh * ww, "r2", gn_single=True)
-        x = resnet("mid_block.resnets.1.", x, None, hh * ww, hh, ww, "r", gn_next=True)   # (-> the first up resnet's norm1: a concat)
+        x = resnet("mid_block.resnets.0.", x, None, hh * ww, hh, ww, "r", gn_next=True)
+        x = transformer("mid_block.attentions.0.", x, hh * ww, "r2")
+        x = resnet("mid_block.resnets.1.", x, None, hh * ww, hh, ww, "r", gn_next=True)
         # ---- 5. up (ref :789-814)
         rev = list(reversed(boc))
         for i, typ in enumerate(cfg.up_block_types):
@@ -734,14 +728,13 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 assert (sh, sw) == (hh, ww)
                 cross = typ == "CrossAttnUpBlock2D"
                 # next consumer: the transformer's norm, the next resnet's norm1, conv_norm_out -- or the upsampling conv (no norm)
-                last = i == nlev - 1 and j == L_   # -> conv_norm_out (a single-input norm; every other norm1 of the up path reads a concat)
                 x = resnet(f"up_blocks.{i}.resnets.{j}.", x, sk, hh * ww, hh, ww, "r" if (j + i) % 2 else "rb",
-                           gn_next=cross or j < L_ or i == nlev - 1, gn_single=cross or last)
+                           gn_next=cross or j < L_ or i == nlev - 1)
                 if cross:
-                    x = transformer(f"up_blocks.{i}.attentions.{j}.", x, hh * ww, "u" if j % 2 else "ub", gn_single=last)
+                    x = transformer(f"up_blocks.{i}.attentions.{j}.", x, hh * ww, "u" if j % 2 else "ub")
             if i != nlev - 1:
                 ho, wo = skips[-1][1], skips[-1][2]      # = (2 hh, 2 ww) unless a down conv rounded an odd size up
-                x = ops.gemm(ops.as_tensor(x).view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
+                x = ops.gemm(x.view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
                              self._buf("us", (B * ho * wo, rev[i])),
                              conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, upsample=1), defer_reduce=True)    # -> the next block's norm1
                 hh, ww = ho, wo

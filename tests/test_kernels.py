@@ -916,148 +916,3 @@ def test_conv_dup_rows_shared_cfg_prefix(backend):
     pwl = ops.pack_linear(rnd(64, 64, seed=1).float(), None, dev)
     with pytest.raises((RuntimeError, AssertionError)):
         ops.gemm(rnd(64, 64, seed=2).to(dev), pwl, torch.empty(128, 64, dtype=BF16, device=dev), dup_rows=64, tile=2)
-
-
-@pytest.mark.parametrize("case", ["conv_temb_t21", "conv_res_t21", "linear_res_t5", "conv_t11", "linear_t4", "conv_s2_t10", "conv_res_t1", "linear_res_t18"])
-def test_groupnorm_statistics_from_the_producing_gemm(backend, monkeypatch, case):
-    """``pcdm_gemm(stats_out)`` + ``pcdm_groupnorm_stats`` (the statistics pass of a GroupNorm moved into the
-    epilogue of the GEMM that produces its input).  The GEMM writes, per (32-row block, wave-column range, group), the sum and the sum of
-    squares of its fp32 outputs; the norm is then the normalise-and-write pass alone.  Checked: (1) the tensor the GEMM writes is
-    bit-identical to the launch without stats_out; (2) the partial sums, folded over blocks and column ranges, against fp64 sums of the
-    fp32 reference; (3) the norm against ``pcdm_groupnorm`` on the same tensor (statistics of the bf16-rounded values there: <= 1 bf16
-    ulp apart) and against fp32 PyTorch; (4) batch entries swapped => outputs swapped, bit for bit (the sums of a 32-row block do not
-    depend on where the entry lies in the tiling).  Shapes: batch entries that are NOT multiples of the M tile (tiles straddle two
-    entries), a last M tile that hangs over M, wave-column ranges that cut groups (tile 5: 32 columns, 20-channel groups), residual /
-    time-embedding-row epilogues."""
-    dev = backend.device
-    monkeypatch.setattr(ops, "STATS_MIN_HW", 32)
-    emu = backend.is_emu
-    conv, stride = case.startswith("conv"), 2 if "_s2_" in case else 1
-    tile = int(case.rsplit("_t", 1)[1])
-    if tile == 21:
-        B, H, Wd, Cin, Cout, G = (3, 11, 32, 64, 320, 32) if emu else (8, 64, 88, 320, 320, 32)
-    elif tile == 5:
-        B, H, Wd, Cin, Cout, G = (3, 11, 32, 64, 160, 8) if emu else (8, 32, 44, 640, 640, 32)
-    elif tile == 11 or tile == 1:
-        B, H, Wd, Cin, Cout, G = (2, 9, 32, 64, 256, 16) if emu else (8, 32, 44, 640, 640, 32)
-    elif tile == 4 or tile == 18:
-        B, H, Wd, Cin, Cout, G = (3, 5, 32, 64, 128, 8) if emu else (8, 32, 44, 640, 640, 32)
-    else:   # 10: stride-2 convolution (Downsample2D), output H x Wd
-        B, H, Wd, Cin, Cout, G = (2, 11, 32, 64, 128, 8) if emu else (8, 32, 44, 320, 320, 32)
-    HW, M = H * Wd, B * H * Wd
-    g = torch.Generator().manual_seed(300 + tile)
-    bias = torch.randn(Cout, generator=g)
-    temb = torch.randn(B, Cout, generator=g) * 2 if "temb" in case else None
-    res = (rnd(M, Cout, seed=311) * 3 + 1.5) if "res" in case else None     # (a mean well away from zero: sum of squares - mean^2 cancels)
-    if conv:
-        Hi, Wi = (2 * H, 2 * Wd) if stride == 2 else (H, Wd)
-        x = rnd(B, Hi, Wi, Cin, seed=312)
-        w = rnd(Cout, Cin, 3, 3, seed=313, scale=1 / math.sqrt(9 * Cin))
-        pw = ops.pack_conv3x3(w.float(), bias, dev)
-        kw = dict(conv=dict(B=B, Hi=Hi, Wi=Wi, Ho=H, Wo=Wd, stride=stride), tile=tile, rows_per_batch=HW)
-        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1, stride=stride).permute(0, 2, 3, 1).reshape(M, Cout)
-    else:
-        x = rnd(M, Cin, seed=312)
-        w = rnd(Cout, Cin, seed=313, scale=1 / math.sqrt(Cin))
-        pw = ops.pack_linear(w.float(), bias, dev)
-        kw = dict(tile=tile, rows_per_batch=HW)
-        ref = x.float() @ w.float().t() + bias
-    if temb is not None:
-        kw.update(rowvec=temb.to(dev))
-        ref = ref + temb.repeat_interleave(HW, 0)
-    if res is not None:
-        kw.update(residual=res.to(dev), res_mod=M)
-        ref = ref + res.float()
-    out_ref = torch.empty(M, Cout, dtype=BF16, device=dev)
-    ops.gemm(x.to(dev), pw, out_ref, **kw)
-    out = torch.full((M, Cout), float("nan"), dtype=BF16, device=dev)
-    sg = ops.gemm(x.to(dev), pw, out, gn_stats=G, **kw)
-    assert isinstance(sg, ops.StatsGemm) and sg.out is out and sg.wn == ops.STATS_TILES[tile]
-    backend.sync()
-    assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16))
-    # (2) the partial sums: [M / 32][Npad / wn][G][2], only the (column range, group) pairs that intersect are defined
-    gs, wn = Cout // G, sg.wn
-    TW = pw.Npad // wn
-    st = sg.stats[: (M // 32) * TW * G * 2].view(B, HW // 32, TW, G, 2).double().cpu()
-    tot = torch.zeros(B, G, 2, dtype=torch.float64)
-    for grp in range(G):
-        for j in range((grp * gs) // wn, ((grp + 1) * gs - 1) // wn + 1):
-            tot[:, grp] += st[:, :, j, grp].sum(1)
-    r = ref.double().view(B, HW, G, gs)
-    want = torch.stack([r.sum((1, 3)), (r * r).sum((1, 3))], -1)
-    scale = (r.abs().sum((1, 3)) + 1).unsqueeze(-1) * torch.tensor([1.0, 1.0])
-    scale[..., 1] = (r * r).sum((1, 3)) + 1
-    assert ((tot - want).abs() <= 2e-3 * scale).all(), ((tot - want).abs() / scale).max().item()   # (bf16 operands against the fp32 reference)
-    # (3) the norm
-    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
-    beta = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-    ws = ops.groupnorm_ws(B, Cout, dev)
-    y_ref = torch.empty(M, Cout, dtype=BF16, device=dev)
-    ops.groupnorm(out_ref, None, B, HW, G, 1e-5, gamma, beta, True, y_ref, ws)
-    y = torch.full((M, Cout), float("nan"), dtype=BF16, device=dev)
-    ops.groupnorm(sg, None, B, HW, G, 1e-5, gamma, beta, True, y, ws)
-    backend.sync()
-    yf, yr = y.float().cpu(), y_ref.float().cpu()
-    assert torch.isfinite(yf).all()
-    assert ((yf - yr).abs() <= 2.0 ** -7 * yr.abs() + 2e-3).all(), (yf - yr).abs().max().item()   # one bf16 ulp + the statistics' rounding
-    assert (yf != yr).float().mean().item() < 0.05
-    want_y = F.silu(F.group_norm(out_ref.float().cpu().view(B, HW, Cout).permute(0, 2, 1), G, gamma.cpu(), beta.cpu(), 1e-5)).permute(0, 2, 1).reshape(M, Cout)
-    assert (yf - want_y).abs().max().item() <= 3e-2
-    # (4) the first two batch entries swapped (input, residual, time-embedding row): the outputs swap, bit for bit
-    perm = [1, 0] + list(range(2, B))
-    xp = x[perm] if conv else x.view(B, HW, Cin)[perm].reshape(M, Cin)
-    kwp = dict(kw)
-    if temb is not None:
-        kwp["rowvec"] = temb[perm].to(dev)
-    if res is not None:
-        kwp["residual"] = res.view(B, HW, Cout)[perm].reshape(M, Cout).contiguous().to(dev)
-    outp = torch.empty(M, Cout, dtype=BF16, device=dev)
-    sgp = ops.gemm(xp.contiguous().to(dev), pw, outp, gn_stats=G, **kwp)
-    yp = torch.empty(M, Cout, dtype=BF16, device=dev)
-    ops.groupnorm(sgp, None, B, HW, G, 1e-5, gamma, beta, True, yp, ws)
-    backend.sync()
-    assert torch.equal(yp.view(B, HW, Cout)[perm].view(torch.int16), y.view(B, HW, Cout).view(torch.int16))
-    # a concat, or another grouping, does not use the statistics (plain pcdm_groupnorm on the tensor)
-    y2 = torch.empty(M, Cout, dtype=BF16, device=dev)
-    ops.groupnorm(sg, None, B, HW, G // 2, 1e-5, gamma, beta, True, y2, ws)
-    y2r = torch.empty(M, Cout, dtype=BF16, device=dev)
-    ops.groupnorm(out_ref, None, B, HW, G // 2, 1e-5, gamma, beta, True, y2r, ws)
-    backend.sync()
-    assert torch.equal(y2.view(torch.int16), y2r.view(torch.int16))
-
-
-def test_gemm_statistics_argument_checks(backend):
-    """stats_out on a launch that cannot write statistics is refused, not ignored: split K, GEGLU, a tile without a statistics instance,
-    batch entries that are not multiples of 32 rows, M not a multiple of 32."""
-    dev = backend.device
-    import ctypes as C_
-    from pcdms_amd import _lib
-    M, K, N = 256, 64, 128
-    a = rnd(M, K, seed=1).to(dev)
-    pw = ops.pack_linear(rnd(N, K, seed=2).float(), torch.zeros(N), dev)
-    out = torch.empty(M, N, dtype=BF16, device=dev)
-    stats = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
-
-    def launch(**over):
-        p = _lib.GemmParams()
-        p.a, p.lda, p.c1, p.w = a.data_ptr(), K, K, pw.w.data_ptr()
-        p.M, p.N, p.K, p.Npad, p.rows_per_batch = M, N, K, pw.Npad, 128
-        p.out, p.ldo, p.tile = out.data_ptr(), N, 4
-        p.stats_out, p.stats_gs = stats.data_ptr(), 16
-        for k, v in over.items():
-            setattr(p, k, v)
-        return _lib.lib().pcdm_gemm(C_.byref(p), ops._stream(a))
-    assert launch() == 0
-    assert launch(tile=2) == -4                      # no statistics instance of the 64 x 64 tile
-    assert launch(tile=34) == -4                     # the A-in-registers kernel
-    assert launch(rows_per_batch=48) == -1           # 32-row blocks must not straddle batch entries
-    assert launch(stats_gs=4) == -1 and launch(stats_gs=24) == -1
-    assert launch(M=240) == -1
-    assert launch(epilogue=ops.EPI_GEGLU) == -1
-    ws = torch.zeros(2 * M * pw.Npad, dtype=torch.float32, device=dev)
-    assert launch(split_k=2, ws=ws.data_ptr(), ws_floats=ws.numel()) == -1
-    wn, n = C_.c_int(0), C_.c_int64(0)
-    assert _lib.lib().pcdm_gemm_stats_geometry(21, 45056, 320, 32, C_.byref(wn), C_.byref(n)) == 0
-    assert (wn.value, n.value) == (80, 1408 * 4 * 32 * 2)
-    assert _lib.lib().pcdm_gemm_stats_geometry(13, 0, 0, 0, None, None) == -1
-    backend.sync()

@@ -21,7 +21,7 @@ def _kwargs(cfg: UNetConfig):
                 attention_head_dim=cfg.attention_head_dim, cross_attention_dim=cfg.cross_attention_dim,
                 use_linear_projection=True, class_embed_type=cfg.class_embed_type,
                 projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim,
-                sample_size=cfg.sample_size, norm_num_groups=cfg.norm_num_groups)
+                sample_size=cfg.sample_size)
 
 
 def _inputs(cfg, B, h, w, L, seed=0):

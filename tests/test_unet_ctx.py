@@ -320,48 +320,3 @@ def test_c_context_starts_with_the_committed_tuning_table():
     assert all(v > 0 for v in seen.values()), seen
     assert lib.pcdm_unet_get_tile(h, 0, 12345, 64, 64, 0, 0, 0, 0, 0, 0, 0, None, None) == -1
     lib.pcdm_unet_destroy(h)
-
-
-def test_producer_statistics_through_both_schedules(backend, monkeypatch):
-    """GroupNorm statistics written by the producing GEMM (``ops.StatsGemm`` / the C schedule's ``stats`` record), at the level of a
-    whole forward: level 0 of a small UNet (8 channels per group, 128 / 1408 rows per batch entry) is put on a tile that has a statistics
-    instance; the Python schedule and ``pcdm_unet_forward`` must then agree BIT FOR BIT with each other (the same launches with the same
-    arguments), and with the forward without the feature (``PCDM_GN_PRODUCER_STATS=0``) to the rounding of the statistics: the sums are
-    taken in front of the bf16 rounding and in another order."""
-    cfg = UNetConfig.tiny(norm_num_groups=8)
-    B, h, w, L, n0 = (2, 8, 16, 5, 1) if backend.is_emu else (4, 32, 44, 9, 2)
-    monkeypatch.setattr(ops, "STATS_MIN_HW", 32)
-    monkeypatch.setenv("PCDM_GN_STATS_MIN_HW", "32")
-
-    class Rec(dict):
-        seen: list = []
-
-        def get(self, k, d=None):
-            self.seen.append(k)
-            return super().get(k, d)
-
-    rec = Rec(ops._TUNED)
-    monkeypatch.setattr(ops, "_TUNED", rec)
-    monkeypatch.setattr(ops, "PRODUCER_STATS", False)
-    monkeypatch.setenv("PCDM_GN_PRODUCER_STATS", "0")
-    _run_both(backend, cfg, B, h, w, L, n0)           # records the problem keys of one forward (and tunes them on the GPU)
-    forced = 0
-    for k in set(rec.seen):
-        if isinstance(k[0], int) and k[0] == B * h * w and k[6] == ops.EPI_STORE and k[1] == 64 and len(k) == 9:   # level 0, N = 64, plain store
-            dict.__setitem__(rec, k, (5, 1))          # 128 x 64 tiles: a statistics instance, <= one batch entry
-            forced += 1
-    assert forced >= 3
-    _, _, ref_py, ref_c = _run_both(backend, cfg, B, h, w, L, n0)
-    assert torch.equal(ref_py, ref_c)
-    monkeypatch.setattr(ops, "PRODUCER_STATS", True)
-    monkeypatch.setenv("PCDM_GN_PRODUCER_STATS", "1")
-    made = []
-    orig = ops.StatsGemm.__init__
-    monkeypatch.setattr(ops.StatsGemm, "__init__", lambda self, **kw: (made.append(kw["out"].shape), orig(self, **kw))[1])
-    _, _, out_py, out_c = _run_both(backend, cfg, B, h, w, L, n0)
-    # level 0: conv1 -> norm2 of 4 unshared resnets (+ the one of the shared-prefix resnet when sharing is off), conv2 -> the transformer's
-    # norm x 5, proj_out -> the next resnet's norm1 / conv_norm_out
-    assert len(made) >= 10, len(made)
-    assert torch.equal(out_py, out_c), (out_py - out_c).abs().max()
-    d = (out_py - ref_py).abs().max().item()
-    assert 0 < d <= 2e-2 * ref_py.abs().max().item(), d

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the feature under test -- GroupNorm statistics from the producing GEMM -- was removed after these sessions: DESIGN.md §7, profiles/r4_gn_producer_stats_ab.txt)
 # round 4, GPU session 7: GroupNorm statistics from the producing GEMM (stats_out / pcdm_groupnorm_stats): kernel and schedule tests on
 # the GPU, producer -> norm pair timings, end-to-end A/B (PCDM_GN_PRODUCER_STATS=0/1 interleaved), full-size parity with the feature on.
 set -u

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the feature under test -- GroupNorm statistics from the producing GEMM -- was removed after these sessions: DESIGN.md §7, profiles/r4_gn_producer_stats_ab.txt)
 # round 4, GPU session 8: what the cross-lane instructions of the statistics reduction do on the hardware (probe), one kernel test with
 # its full report, the norms alone, and the per-kernel times of a step with the feature on (rocprofv3 kernel trace).
 set -u

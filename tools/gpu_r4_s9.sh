@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the feature under test -- GroupNorm statistics from the producing GEMM -- was removed after these sessions: DESIGN.md §7, profiles/r4_gn_producer_stats_ab.txt)
 # round 4, GPU session 9: the statistics reduction with the inline-asm lane swaps (tools/debug_stats.py, the kernel and schedule tests),
 # producer -> norm pair timings and the norms alone, end-to-end A/B (PCDM_GN_PRODUCER_STATS=0/1 interleaved).
 set -u
