@@ -351,11 +351,7 @@ def cpu_baseline(N, ddim_steps):
       * ``config1``: BASELINE.json configs[0] in FULL -- one 256x256 pair (latent 32x64), N = 1, 20 DDIM steps, guidance 2.0, fp32."""
     import subprocess
     topo = host_topology()
-    counts = {c for c in (8, 16, 32, 64) if c <= topo["physical_cores"]} | {min(8, topo["physical_cores"])}
-    quota = topo.get("cgroup_cpu_quota_cores")
-    if quota:    # a CPU-bandwidth quota below the visible core count: threads beyond it only take turns (64 threads slower than 32 in round 3 / 4)
-        counts = {c for c in counts if c <= 2 * quota} | {max(1, min(int(quota), topo["physical_cores"]))}
-    counts = sorted(counts)
+    counts = baseline_thread_counts(topo)
     # explicit places, one per physical core, NUMA node 0's cores first: thread i of the child's OpenMP team is bound to cpus[i], so a
     # run with n threads uses exactly the first n cores of that order (computed HERE: once OMP_PROC_BIND is in the environment the
     # child's own main thread is already bound to one CPU when it could look)
@@ -377,6 +373,17 @@ def cpu_baseline(N, ddim_steps):
                       f"1 warm-up + 2 timed steps per thread count, threads pinned one per physical core (OMP_PROC_BIND=close, explicit OMP_PLACES, NUMA node 0's cores first); {per_step:.2f} s/step at {best} threads, extrapolated x{ddim_steps}",
             "host": doc["host"], "per_thread_count": doc["per_thread_count"], "config1": doc["config1"],
             "note": "a reported baseline, not a target: one host process; the GPU line is whole-job throughput of N images per call"}
+
+
+def baseline_thread_counts(topo):
+    """Thread counts of the CPU-baseline sweep: 8 / 16 / 32 / 64 where the host has the cores; with a cgroup CPU-bandwidth quota below the
+    visible core count (threads beyond it only take turns: 64 threads measured slower than 32 in rounds 3 / 4 on a 16-core quota) the
+    quota's core count is added and counts beyond twice the quota are dropped."""
+    counts = {c for c in (8, 16, 32, 64) if c <= topo["physical_cores"]} | {min(8, topo["physical_cores"])}
+    quota = topo.get("cgroup_cpu_quota_cores")
+    if quota:
+        counts = {c for c in counts if c <= 2 * quota} | {max(1, min(int(quota), topo["physical_cores"]))}
+    return sorted(counts)
 
 
 def cpu_baseline_worker():
@@ -432,10 +439,10 @@ def cpu_baseline_worker():
                                   "threads": int(best), "seconds": round(c1_s, 2), "images_per_s": round(1.0 / c1_s, 5)}}), flush=True)
 
 
-def cgroup_cpu_quota():
+def cgroup_cpu_quota(root: Path = Path("/sys/fs/cgroup")):
     """CPU-bandwidth quota of this container in cores (cgroup v2 ``cpu.max`` / v1 ``cpu.cfs_quota_us``), or None when unlimited / unreadable."""
     try:
-        txt = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        txt = (root / "cpu.max").read_text().split()
         if txt and txt[0] != "max":
             return round(int(txt[0]) / int(txt[1]), 2)
         if txt:
@@ -443,8 +450,8 @@ def cgroup_cpu_quota():
     except (OSError, ValueError, IndexError):
         pass
     try:
-        q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
-        per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        q = int((root / "cpu" / "cpu.cfs_quota_us").read_text())
+        per = int((root / "cpu" / "cpu.cfs_period_us").read_text())
         return round(q / per, 2) if q > 0 and per > 0 else None
     except (OSError, ValueError):
         return None

@@ -116,3 +116,27 @@ def test_bench_runs_with_a_one_rank_rccl_group():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["value"] > 0
     assert d["config"]["rccl_world_size"] == 1 and d["config"]["process_group"] == "nccl" and d["config"]["hipgraph"] is True
+
+
+def test_cpu_baseline_thread_counts_follow_the_cgroup_quota(tmp_path):
+    """The host leg of bench.py: the container's CPU-bandwidth quota (cgroup v2 ``cpu.max`` / v1 ``cpu.cfs_quota_us``) is read and bounds
+    the thread-count sweep -- the GPU boxes show 256 CPUs and grant 16 cores, which is why 64 threads measured slower than 32."""
+    import bench
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert bench.cgroup_cpu_quota(tmp_path) == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cgroup_cpu_quota(tmp_path) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cgroup_cpu_quota(v1) is None
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("350000\n")
+    assert bench.cgroup_cpu_quota(v1) == 3.5
+    assert bench.cgroup_cpu_quota(tmp_path / "missing") is None
+    topo = {"physical_cores": 128, "cgroup_cpu_quota_cores": 16.0}
+    assert bench.baseline_thread_counts(topo) == [8, 16, 32]
+    assert bench.baseline_thread_counts({"physical_cores": 128, "cgroup_cpu_quota_cores": None}) == [8, 16, 32, 64]
+    assert bench.baseline_thread_counts({"physical_cores": 8, "cgroup_cpu_quota_cores": None}) == [8]
+    assert bench.baseline_thread_counts({"physical_cores": 64, "cgroup_cpu_quota_cores": 3.5}) == [3]
+    assert bench._parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
