@@ -22,6 +22,7 @@ extern "C" {
 
 typedef void* pcdm_stream_t; /* hipStream_t */
 
+#define PCDM_ABI_VERSION 2   /* what pcdm_version() returns for the library this header belongs to */
 int pcdm_version(void);
 /* 1 only for the test-only CPU lane emulator build (tests/emu); the product .so returns 0. */
 int pcdm_is_emulator(void);
@@ -142,7 +143,11 @@ typedef struct pcdm_gemm_params {
                               N % 8 == 0, ldo % 8 == 0, rows_per_batch >= 32 and dup_rows % rows_per_batch == 0 with a rowvec; else -1 */
 } pcdm_gemm_params;
 /* pcdm_version() == 2: the struct above ends with defer_reduce, rowvec_step, rowvec_step_stride, dup_rows (1: ended with ln_eps).  Zero-initialise it (memset) and build against
- * the header of the library in use: a host compiled against an older header passes a shorter struct. */
+ * the header of the library in use: a host compiled against an older header passes a shorter struct.  A host MUST compare
+ * pcdm_version() with the PCDM_ABI_VERSION it was compiled against before its first pcdm_gemm call (the library reads the trailing fields
+ * unconditionally).  bias, rowvec, ldrv and rowvec_step_stride must keep 16-byte alignment (4 floats): the epilogues load them as
+ * float4; a violation returns -1.  *rowvec_step must stay below the number of blocks behind rowvec -- it is device memory the library
+ * cannot validate at launch. */
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 
 /* ---- K9/K10 fused attention (replaces xformers.ops.memory_efficient_attention enabled at
@@ -301,7 +306,9 @@ int pcdm_unet_set_shared_cfg_input(pcdm_unet* u, void* workspace, int shared);
  * ResnetBlock2D.time_emb_proj for ALL n timesteps of t_dev, once per sampling call (2 + 2 ceil(n / 32) + 2 launches) instead of five launches
  * per denoise step.  table: caller-owned device memory of pcdm_unet_time_table_bytes(u, n, B) bytes, alive while forwards use it.
  * pcdm_unet_forward calls on this workspace that pass the same t_dev and a device step counter pick their block by that counter; any other
- * call computes the embeddings per step as before.  Bit-identical to the per-step launches. */
+ * call computes the embeddings per step as before.  Bit-identical to the per-step launches.  The table is keyed on the POINTER t_dev: a host
+ * that rewrites the timestep buffer in place (another schedule or step count) must call pcdm_unet_prepare_timesteps again before the
+ * next forward, and the device step counter must stay below n (neither is checkable at launch: both live in device memory). */
 int64_t pcdm_unet_time_table_bytes(const pcdm_unet* u, int n, int B);
 int pcdm_unet_prepare_timesteps(pcdm_unet* u, const int64_t* t_dev, int n, void* table, void* workspace, pcdm_stream_t s);
 /* x_in NHWC bf16 [B, h, w, conv_in.cin] (pcdm_assemble_input / pcdm_nchw_f32_to_nhwc_bf16); timestep = t_dev[step_dev ? *step_dev : 0] (device);

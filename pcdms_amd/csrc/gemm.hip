@@ -1021,6 +1021,9 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     if (!p || !p->a || !p->w || !p->out) return -1;
     if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->K % BK || p->Npad % 64 || p->Npad < p->N || p->N % 4) return -1;
     if (p->rows_per_batch <= 0) return -1;
+    // 16-byte vector loads of the epilogue operands: bias and rowvec bases, the row pitch and the per-step block stride
+    if (((uintptr_t)p->bias & 15) || (p->rowvec && (((uintptr_t)p->rowvec & 15) || (p->ldrv > 0 && p->ldrv % 4) || (p->rowvec_step && p->rowvec_step_stride % 4))))
+        return -1;
     // 32-bit buffer offsets: every operand must stay below 2 GiB
     const int64_t lim = 0x7fffffffLL;
     if ((int64_t)p->Npad * (p->ldw > 0 ? p->ldw : p->K) * 2 >= lim) return -2;

@@ -120,12 +120,24 @@ __global__ __launch_bounds__(kThreads) void gn_reduce_kernel(const GnSrc s, int 
     *(u16x8*)(s.pre_out + row * s.C1 + c) = gn_src_load<true>(s, (int)(row / HW), row, c);
 }
 
-// part: [B][nchunk][groups][2]  per-(row-chunk, group) partial {sum, sum of squares}, fixed summation order
+// part: [B][nchunk][groups][2]  per-(row-chunk, group) partial {mean, M2 = sum of squares centred at that mean}, fixed merge order.
+// Robust to |mean| >> std (checkpoint-like statistics; rounds 1-4 wrote {sum, sum of squares} and took E[x^2] - mean^2): a thread sums
+// its rows of a channel SHIFTED by the first value it loads (x - K is of the size of the spread, so K + s/n and q - s^2/n lose
+// nothing), and every merge -- the row-lanes of a channel, the channels of a group, the chunks in gn_apply -- is Chan's
+// {n, mean, M2} update.
+__device__ __forceinline__ void gn_chan_merge(float& n, float& mean, float& m2, float nj, float mj, float m2j) {
+    if (nj <= 0.f) return;
+    const float tot = n + nj, d = mj - mean, w = nj / tot;
+    mean += d * w;
+    m2 += m2j + d * d * n * w;
+    n = tot;
+}
+
 __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restrict__ x1, int C1,
                                                           const u16* __restrict__ x2, int C2, int HW,
                                                           int rows_per_chunk, int groups, float* __restrict__ part) {
     __shared__ float red[kThreads * 16];
-    __shared__ float chs[kGnMaxC], chq[kGnMaxC];   // per-channel sums of this block's row chunk
+    __shared__ float chs[kGnMaxC], chq[kGnMaxC];   // per-channel {mean, M2} of this block's row chunk
     const int C = C1 + C2;
     const GnGeom g = gn_geom(C);
     const int t = threadIdx.x;
@@ -134,61 +146,64 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const u16* __restric
     const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = (r0 + rows_per_chunk < HW) ? r0 + rows_per_chunk : HW;
+    // rows this thread's row-lane walks: r0 + rp, + rows_par, ... < r1
+    auto lane_rows = [&](int j) { const int f = r0 + j; return f < r1 ? (r1 - f + g.rows_par - 1) / g.rows_par : 0; };
     for (int ocb = 0; ocb < g.noct; ocb += g.tpr) {
         const int oc = ocb + oc0;
-        float s[8], q[8];
+        float s[8], q[8], K[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-        if (active && oc < g.noct) {
+        for (int e = 0; e < 8; ++e) s[e] = q[e] = K[e] = 0.f;
+        if (active && oc < g.noct && r0 + rp < r1) {
+            const u16x8 k8 = gn_load(x1, C1, x2, C2, (int64_t)b * HW + r0 + rp, oc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) K[e] = bf2f(k8[e]);
             for (int r = r0 + rp; r < r1; r += kGnUnroll * g.rows_par) {
                 u16x8 v[kGnUnroll];
 #pragma unroll
                 for (int u = 0; u < kGnUnroll; ++u) {
                     const int rr = r + u * g.rows_par;
-                    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    v[u] = rr < r1 ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + rr, oc * 8) : z;
+                    v[u] = rr < r1 ? gn_load(x1, C1, x2, C2, (int64_t)b * HW + rr, oc * 8) : k8;   // (x - K = 0 beyond the chunk)
                 }
 #pragma unroll
                 for (int u = 0; u < kGnUnroll; ++u)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float f = bf2f(v[u][e]);
+                        const float f = bf2f(v[u][e]) - K[e];
                         s[e] += f;
                         q[e] += f * f;
                     }
             }
         }
         __syncthreads();  // previous iteration's readers are done with `red`
+        {
+            const float nt = (float)lane_rows(rp), inv = nt > 0.f ? 1.0f / nt : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[t * 16 + e] = s[e];
-            red[t * 16 + 8 + e] = q[e];
+            for (int e = 0; e < 8; ++e) {
+                red[t * 16 + e] = K[e] + s[e] * inv;                 // mean of this thread's rows
+                red[t * 16 + 8 + e] = q[e] - s[e] * s[e] * inv;      // M2 about it
+            }
         }
         __syncthreads();
         if (rp == 0 && oc < g.noct) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float ss = 0.f, qq = 0.f;
-                for (int j = 0; j < g.rows_par; ++j) {
-                    ss += red[(j * g.tpr + oc0) * 16 + e];
-                    qq += red[(j * g.tpr + oc0) * 16 + 8 + e];
-                }
-                chs[oc * 8 + e] = ss;
-                chq[oc * 8 + e] = qq;
+                float n = 0.f, mean = 0.f, m2 = 0.f;
+                for (int j = 0; j < g.rows_par; ++j)
+                    gn_chan_merge(n, mean, m2, (float)lane_rows(j), red[(j * g.tpr + oc0) * 16 + e], red[(j * g.tpr + oc0) * 16 + 8 + e]);
+                chs[oc * 8 + e] = mean;
+                chq[oc * 8 + e] = m2;
             }
         }
     }
     __syncthreads();
     const int gs = C / groups;
+    const float nrow = (float)(r1 - r0);
     for (int grp = t; grp < groups; grp += kThreads) {
-        float ss = 0.f, qq = 0.f;
-        for (int c = grp * gs; c < (grp + 1) * gs; ++c) {
-            ss += chs[c];
-            qq += chq[c];
-        }
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int c = grp * gs; c < (grp + 1) * gs; ++c) gn_chan_merge(n, mean, m2, nrow, chs[c], chq[c]);
         float* ps = part + (((int64_t)b * nchunk + chunk) * groups + grp) * 2;
-        ps[0] = ss;
-        ps[1] = qq;
+        ps[0] = mean;
+        ps[1] = m2;
     }
 }
 
@@ -211,30 +226,49 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const u16* __restric
     // thread (sub, grp) sums chunks sub, sub+NSUB, ... with its loads in flight together (a serial 64-deep chain of
     // dependent L2 round trips per group cost more than the streaming pass on the small instances), then the NSUB
     // partials are combined in fp64.
-    __shared__ double psum[kThreads * 2];
+    __shared__ double psum[kThreads * 3];
     {
+        // Chan merge of the chunks' {mean, M2} (n_i = rows of chunk i x gs) in fp64, fixed order
+        auto chunk_n = [&](int ch) {
+            const int c0 = ch * rows_per_chunk;
+            const int c1 = (c0 + rows_per_chunk < HW) ? c0 + rows_per_chunk : HW;
+            return c1 > c0 ? (double)(c1 - c0) * gs : 0.0;
+        };
+        auto merge = [](double& n, double& mean, double& m2, double nj, double mj, double m2j) {
+            if (nj <= 0.0) return;
+            const double tot = n + nj, d = mj - mean, w = nj / tot;
+            mean += d * w;
+            m2 += m2j + d * d * n * w;
+            n = tot;
+        };
         const int nsub = kThreads / groups > 0 ? kThreads / groups : 1;   // groups <= 256
         const int sub = t / groups, grp = t - sub * groups;
-        double s = 0.0, q = 0.0;
+        double n = 0.0, mean = 0.0, m2 = 0.0;
         if (sub < nsub) {
-            for (int ch = sub; ch < nchunk; ch += nsub) {
-                const float* ps = part + (((int64_t)b * nchunk + ch) * groups + grp) * 2;
-                s += (double)ps[0];
-                q += (double)ps[1];
+            for (int ch0 = sub; ch0 < nchunk; ch0 += 8 * nsub) {   // eight independent loads in flight, then their (serial) merges
+                float pm[8], pq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ch = ch0 + u * nsub;
+                    const float* ps = part + (((int64_t)b * nchunk + (ch < nchunk ? ch : 0)) * groups + grp) * 2;
+                    pm[u] = ps[0];
+                    pq[u] = ps[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ch = ch0 + u * nsub;
+                    if (ch < nchunk) merge(n, mean, m2, chunk_n(ch), (double)pm[u], (double)pq[u]);
+                }
             }
         }
-        psum[2 * t] = s;
-        psum[2 * t + 1] = q;
+        psum[3 * t] = n;
+        psum[3 * t + 1] = mean;
+        psum[3 * t + 2] = m2;
         __syncthreads();
         if (t < groups) {
-            s = q = 0.0;
-            for (int j = 0; j < nsub; ++j) {
-                s += psum[2 * (j * groups + t)];
-                q += psum[2 * (j * groups + t) + 1];
-            }
-            const double cnt = (double)HW * gs;
-            const double mean = s / cnt;
-            double var = q / cnt - mean * mean;
+            n = mean = m2 = 0.0;
+            for (int j = 0; j < nsub; ++j) merge(n, mean, m2, psum[3 * (j * groups + t)], psum[3 * (j * groups + t) + 1], psum[3 * (j * groups + t) + 2]);
+            double var = n > 0.0 ? m2 / n : 0.0;
             if (var < 0.0) var = 0.0;
             stat[2 * t] = (float)mean;
             stat[2 * t + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -460,9 +494,11 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, in
             if (r < r1) *(u16x8*)(src.pre_out + ((int64_t)b * HW + r) * src.C1 + c) = v[i];
         }
     }
-    // ---- this chunk's per-group sum and sum of squares (rows beyond the chunk hold zeros)
-    // (two passes over the packed registers: sums, then sums of squares -- holding both sets of accumulators and the slab
-    //  at once spills at 128 registers)
+    // ---- this chunk's per-group sum, then the sum of squares CENTRED at the chunk's own mean (exact two-pass on the registers; rows beyond
+    // the chunk hold zeros and are masked out of the second pass).  The partners exchange {sum, centred M2} and every workgroup merges
+    // them with Chan's formula in fp64: M2 = sum_i M2_i + n_i (mean_i - mean)^2.  (Rounds 3-4 exchanged {sum, sum of squares} and took
+    // E[x^2] - mean^2: with |mean| >> std -- checkpoint-like statistics -- the fp32 partial sums of squares lose mean^2 / var of their
+    // precision; tests/test_kernels.py::test_groupnorm_large_mean.)
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, qg[4] = {0.f, 0.f, 0.f, 0.f};
     {
         float s[8];
@@ -481,16 +517,24 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, in
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) GN_KEEP_PACKED(v[i]);
     {
-        float q[8];
+        const float inv_nloc = 1.0f / ((float)(r1 - r0) * (float)gs);   // (r1 > r0: the launcher's chunks are never empty)
+        float mloc[8], q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            mloc[e] = sg[ge[e] & 3] * inv_nloc;
+            q[e] = 0.f;
+        }
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i)
+        for (int i = 0; i < MAXR; ++i) {
+            const int r = r0 + rp + i * rows_par;
+            if (active && r < r1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = bf2f(v[i][e]);
-                q[e] += f * f;
+                for (int e = 0; e < 8; ++e) {
+                    const float d = bf2f(v[i][e]) - mloc[e];
+                    q[e] += d * d;
+                }
             }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
@@ -505,7 +549,18 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, in
     // (payload by SYSTEM-scope accesses -- write-through stores drained before the ticket, loads served by memory after the poll: no
     //  release / acquire FENCE, whose L2 write-back of the previous kernel's still-dirty output cost ~7 us per launch here.  Agent
     //  scope is not enough for the loads across XCDs: see pcdm_load_sys.)
-    if (t < 8) pcdm_store_sys(part + chunk * 8 + t, (t & 1) ? qg[t >> 1] : sg[t >> 1]);
+    {   // thread t < 8 publishes entry t of {s0, q0, s1, q1, ...}: selected by compare chains -- indexing sg[] / qg[] with the lane id put
+        // both arrays into a 48-byte scratch frame, i.e. a scratch round trip at the head of the exchange
+        float pv = sg[0];
+        pv = t == 1 ? qg[0] : pv;
+        pv = t == 2 ? sg[1] : pv;
+        pv = t == 3 ? qg[1] : pv;
+        pv = t == 4 ? sg[2] : pv;
+        pv = t == 5 ? qg[2] : pv;
+        pv = t == 6 ? sg[3] : pv;
+        pv = t == 7 ? qg[3] : pv;
+        if (t < 8) pcdm_store_sys(part + chunk * 8 + t, pv);
+    }
     pcdm_drain_vmem();
     __syncthreads();
     // BOUNDED poll: the launcher checked that the grid fits the device (occupancy x CUs), but a plain launch cannot promise co-residency
@@ -526,35 +581,65 @@ __global__ __launch_bounds__(THREADS) void gn_cluster_kernel(const GnSrc src, in
     __syncthreads();
     const bool alone = stat_flag[0] != 0;   // block-uniform
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (alone) {
+    if (alone) {   // two passes over the whole slab: sums, then squares centred at the slab mean
         for (int r = rp; r < HW && active; r += rows_par) {
             const u16x8 z = gn_src_load<SK>(src, b, (int64_t)b * HW + r, c);   // (split-K source: recomputed, same value)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = bf2f(z[e]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    fs[k] += (ge[e] == k) ? f : 0.f;
-                    fq[k] += (ge[e] == k) ? f * f : 0.f;
-                }
+                for (int k = 0; k < 4; ++k) fs[k] += (ge[e] == k) ? f : 0.f;
             }
         }
         gn_block_sum4<THREADS>(fs, gpb, red);
+        float ma[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ma[e] = (float)((double)fs[ge[e] & 3] * inv_n);
+        for (int r = rp; r < HW && active; r += rows_par) {
+            const u16x8 z = gn_src_load<SK>(src, b, (int64_t)b * HW + r, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = bf2f(z[e]) - ma[e];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fq[k] += (ge[e] == k) ? d * d : 0.f;
+            }
+        }
         gn_block_sum4<THREADS>(fq, gpb, red);
     }
     if (t < gpb) {
-        double ss = 0.0, qq = 0.0;
+        double mean, m2;
         if (alone) {
-            ss = (double)(t == 0 ? fs[0] : t == 1 ? fs[1] : t == 2 ? fs[2] : fs[3]);
-            qq = (double)(t == 0 ? fq[0] : t == 1 ? fq[1] : t == 2 ? fq[2] : fq[3]);
+            mean = (double)(t == 0 ? fs[0] : t == 1 ? fs[1] : t == 2 ? fs[2] : fs[3]) * inv_n;
+            m2 = (double)(t == 0 ? fq[0] : t == 1 ? fq[1] : t == 2 ? fq[2] : fq[3]);
         } else {
-            for (int ch = 0; ch < S; ++ch) {
-                ss += (double)pcdm_load_sys(part + ch * 8 + 2 * t);
-                qq += (double)pcdm_load_sys(part + ch * 8 + 2 * t + 1);
+            // fixed chunk order, fp64: bit-identical in every workgroup of the slab and run to run.  (S <= 8; the loops are fully unrolled
+            // over 8 with a guard so that ps / pq are indexed by constants and stay in registers)
+            float ps[8], pq[8];
+            double ss = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                ps[ch] = pq[ch] = 0.f;
+                if (ch < S) {
+                    ps[ch] = pcdm_load_sys(part + ch * 8 + 2 * t);
+                    pq[ch] = pcdm_load_sys(part + ch * 8 + 2 * t + 1);
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) ss += (double)ps[ch];
+            mean = ss * inv_n;
+            m2 = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                if (ch < S) {
+                    const int c0 = ch * rows_per_chunk;
+                    const int c1 = (c0 + rows_per_chunk < HW) ? c0 + rows_per_chunk : HW;
+                    const float n_f = (float)(c1 - c0) * (float)gs;                 // (exact: < 2^24)
+                    const double d = (double)(ps[ch] / n_f) - mean;                 // chunk mean (fp32 divide: 0.5 ulp) - slab mean
+                    m2 += (double)pq[ch] + (double)n_f * d * d;
+                }
             }
         }
-        const double mean = ss * inv_n;            // (fp64 multiplies only: fp64 divide / sqrt sequences cost ~40 registers here)
-        double var = qq * inv_n - mean * mean;
+        double var = m2 * inv_n;
         if (var < 0.0) var = 0.0;
         stat[2 * t] = (float)mean;
         stat[2 * t + 1] = 1.0f / sqrtf((float)var + eps);
@@ -910,7 +995,8 @@ extern "C" int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* p, const void* x2
     const int C1 = p->N, C = C1 + C2;
     if (C1 <= 0 || C1 % 8 || C2 % 8 || C % groups || C > kGnMaxC || (C2 > 0 && !x2)) return -1;
     if (p->split_k < 2 || p->split_k > 64 || p->Npad < C1 || p->Npad % 8 || p->M != B * HW) return -1;
-    if ((p->rowvec && (p->ldrv % 4 || ((uintptr_t)p->rowvec & 15))) || (p->residual && (p->ldr < C1 || p->ldr % 8))) return -1;
+    if ((p->rowvec && (p->ldrv % 4 || ((uintptr_t)p->rowvec & 15) || (p->rowvec_step && p->rowvec_step_stride % 4))) || ((uintptr_t)p->bias & 15) ||
+        (p->residual && (p->ldr < C1 || p->ldr % 8))) return -1;
     GnSrc src{};
     src.x1 = (const u16*)p->pre_out; src.C1 = C1; src.x2 = (const u16*)x2; src.C2 = C2;
     src.part = p->part; src.S = p->split_k; src.ldp = p->Npad; src.slab = (int64_t)p->M * p->Npad;

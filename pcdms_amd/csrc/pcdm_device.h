@@ -182,7 +182,8 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) { return f32x2{gelu_erf_f(
 __device__ __forceinline__ float gelu_erf_f(float x) {
     const float t = fminf(fabsf(x), 6.0f);
     const float q = PCDM_GELU_Q0 + t * (PCDM_GELU_Q1 + t * (PCDM_GELU_Q2 + t * (PCDM_GELU_Q3 + t * (PCDM_GELU_Q4 + t * PCDM_GELU_Q5))));
-    return fmaxf(x, 0.f) - t * fast_exp2(q);
+    // (x > 0 ? x : x != x ? x : 0: fmaxf / fminf drop a NaN operand, which laundered an overflowed gate into a finite output -- ADVICE r4)
+    return (x > 0.f ? x : (x != x ? x : 0.f)) - t * fast_exp2(q);
 }
 __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
     const f32x2 t = {fminf(fabsf(x[0]), 6.0f), fminf(fabsf(x[1]), 6.0f)};
@@ -192,7 +193,7 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
     q = q * t + PCDM_GELU_Q1;
     q = q * t + PCDM_GELU_Q0;
     const f32x2 e = {fast_exp2(q[0]), fast_exp2(q[1])};
-    const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    const f32x2 r = {x[0] > 0.f ? x[0] : (x[0] != x[0] ? x[0] : 0.f), x[1] > 0.f ? x[1] : (x[1] != x[1] ? x[1] : 0.f)};   // NaN-propagating max(x, 0)
     return r - t * e;
 }
 #endif

@@ -401,7 +401,17 @@ extern "C" pcdm_unet* pcdm_unet_create(const pcdm_unet_config* cfg) {
     static const int kTable[][13] = {
 #include "tuning_table.inc"
     };
-    for (const auto& r : kTable) u->tiles[TileKey{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]}] = {r[11], r[12]};
+    // ... on the architecture it was measured on only: any other device starts on pcdm_gemm's static heuristic
+    bool gfx950 = true;
+#ifndef PCDM_EMU
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        gfx950 = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    }
+#endif
+    if (gfx950)
+        for (const auto& r : kTable) u->tiles[TileKey{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]}] = {r[11], r[12]};
     return u;
 }
 

@@ -366,6 +366,12 @@ class Stage2_InpaintDiffusionPipeline:
                 st["step"].zero_()
                 self._zero_history(st)
                 self._ctx.sync_tiles()
+                # the eager step may have grown the split-K workspace (-> a new workspace generation): store the generation AFTER it, or
+                # the next call would tune a second time
+                w_gen2 = (id(unet), getattr(unet, "_pack_gen", 0), ops.workspace_generation(dev))
+                if w_gen2 != w_gen:
+                    self._graph = None        # (a graph captured on the old workspace addresses must not be replayed)
+                w_gen = w_gen2
                 st["c_tuned"] = (id(self._ctx), w_gen)
             st["pose_b"] = self._ctx.prepare_conditioning(B, h, w, feature_f, prior_embed, pose_cond, zero_ctx_batches=n0,
                                                           shared_cfg_input=st["cond"].shared_halves)

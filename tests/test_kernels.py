@@ -76,6 +76,37 @@ def test_groupnorm(backend, case):
         close(out.view(B, HW, C), ref.permute(0, 2, 1))
 
 
+@pytest.mark.parametrize("case", ["fused", "two_pass", "cluster"])
+def test_groupnorm_large_mean(backend, case):
+    """Checkpoint-like statistics: every channel offset by 50 standard deviations, per-channel offsets on top, so
+    that E[x^2] - mean^2 in fp32 would lose 2500 x of its precision.  All three GroupNorm paths against an fp64 reference on the same
+    bf16 inputs: the single-pass kernel (centred two-pass on registers), the two-kernel path (shifted sums + Chan merges) and -- GPU
+    only -- the cluster kernel (centred chunk statistics + Chan merge across the partner workgroups)."""
+    dev = backend.device
+    if case == "fused":
+        B, HW, C, G = (2, 300, 80, 8) if backend.is_emu else (8, 32 * 44, 640, 32)
+    elif case == "two_pass":
+        B, HW, C, G = (1, 3000, 48, 4) if backend.is_emu else (8, 64 * 88, 960, 32)
+    else:
+        if backend.is_emu:
+            pytest.skip("the cluster kernel needs co-resident workgroups: GPU only")
+        B, HW, C, G = 8, 64 * 88, 320, 32
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(B * HW, C, generator=g)                           # unit spread
+    chan = torch.randn(1, C, generator=g) * 3.0                          # per-channel offsets inside a group
+    x = (base + chan + 50.0).to(BF16)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 3.0                             # (GroupNorm beta ~ N(0, 3^2))
+    out = torch.empty(B * HW, C, dtype=BF16, device=dev)
+    ws = ops.groupnorm_ws(B, C, dev)
+    ops.groupnorm(x.to(dev), None, B, HW, G, 1e-5, gamma.to(dev), beta.to(dev), False, out, ws)
+    backend.sync()
+    xr = x.double().view(B, HW, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, G, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1)
+    # the statistic itself: recover rstd-scaled values and compare tightly (bf16 output rounding is 2^-9 of |out| <= ~12)
+    close(out.view(B, HW, C), ref, tol=6e-3)
+
+
 def test_layernorm(backend):
     dev = backend.device
     for rows, C in ([(9, 64), (13, 320), (7, 640), (3, 1280), (5, 768), (2, 1536), (3, 2048)] if backend.is_emu else
@@ -761,6 +792,31 @@ def test_rowgemm_thin_k(backend):
     pw64 = ops.pack_linear(rnd(64, 64, seed=1).float(), None, dev)
     with pytest.raises(RuntimeError):
         ops.gemm(rnd(32, 64, seed=2).to(dev), pw64, torch.empty(32, 64, dtype=BF16, device=dev), tile=31)
+
+
+def test_rowgemm_folded_layernorm_large_mean(backend):
+    """The folded LayerNorm ``rstd (x W'^T - mean wsum) + b'`` (rowgemm.hip) on rows whose |mean| / std is 50 (the
+    cancellation between the two terms grows with |mean| / std).  Both terms are exact bf16 products accumulated in fp32, so the
+    difference keeps ~2^-24 x 50 relative accuracy; the test states it: against LayerNorm (fp64, on the same bf16 rows) -> fp64 GEMM,
+    within the kernels' usual 1 % (what remains is the bf16 rounding of W' = W diag(gamma) and of the output)."""
+    dev = backend.device
+    K = 320
+    g = torch.Generator().manual_seed(190)
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 3.0      # LayerNorm beta ~ N(0, 3^2)
+    M, N = (100, 128) if backend.is_emu else (45056, 960)
+    sign = torch.where(torch.rand(M, 1, generator=g) < 0.5, -1.0, 1.0)
+    a = (torch.randn(M, K, generator=g) + 50.0 * sign).to(BF16)                           # every row: |mean| = 50 std
+    w = rnd(N, K, seed=192, scale=1 / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    pw = ops.pack_linear(w.float(), bias, dev)
+    pw_ln = ops.pack_linear_ln(w.float(), bias, gamma, beta, dev)
+    ref = F.layer_norm(a.double(), (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + bias.double()
+    for tile in (34, 32):
+        out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+        ops.gemm(a.to(dev), pw, out, tile=tile, ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, K, dtype=BF16, device=dev),
+                 pw_ln=pw_ln)
+        backend.sync()
+        close(out, ref)
 
 
 def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:
