@@ -185,6 +185,28 @@ def synth_state_dict(cfg: UNetConfig, seed: int = 0, random_affine: bool = False
     return sd
 
 
+def stress_state_dict(cfg: UNetConfig, seed: int = 0, n_outlier: int = 8, gain: float = 30.0, beta_std: float = 3.0) -> Dict[str, Tensor]:
+    """``synth_state_dict(cfg, seed, random_affine=True)`` reshaped to have the activation statistics of a TRAINED checkpoint, which
+    the U(+-1/sqrt(fan_in)) weights do not (VERDICT r4 weak #1 / next #4b): ``n_outlier`` output channels of ``conv_in``, of every
+    ``proj_in`` and of every ``ff.net.2`` carry ``gain`` x the weight and bias (outlier channels in the residual stream: rows whose
+    |mean| >> std reach every LayerNorm, groups with a dominant channel every GroupNorm), and every GroupNorm / LayerNorm beta is
+    drawn from N(0, beta_std^2).  Deterministic in (seed, key): the GPU box regenerates it."""
+    sd = synth_state_dict(cfg, seed, random_affine=True)
+    shapes = dict(param_shapes(cfg))
+    for key in list(sd):
+        g = torch.Generator(device="cpu")
+        g.manual_seed((seed * 1000003 + zlib.crc32(("stress:" + key).encode())) & 0x7FFFFFFF)
+        stem = key[: key.rfind(".") + 1]
+        if len(shapes[stem + "weight"]) == 1:
+            if key.endswith("bias"):
+                sd[key] = torch.randn(sd[key].shape, generator=g) * beta_std
+        elif key == "conv_in.weight" or key.endswith(".proj_in.weight") or key.endswith(".ff.net.2.weight"):
+            idx = torch.randperm(sd[key].shape[0], generator=g)[:n_outlier]
+            sd[key][idx] *= gain
+            sd[stem + "bias"][idx] *= gain
+    return sd
+
+
 # ----------------------------------------------------------------------------- blocks [D-0.24]
 def timestep_embedding(t: Tensor, dim: int, flip_sin_to_cos: bool = True, shift: float = 0.0) -> Tensor:
     """Appendix A-1 (diffusers ``Timesteps``; built at ref :184)."""

@@ -575,6 +575,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
 
     # -- the schedule proper; x_in is NHWC bf16 [B,h,w,cin_pad]; returns fp32 NCHW eps (a reused buffer)
     def _forward_nhwc(self, x_in, B, h, w, timestep, cond: Conditioning, step_dev=None) -> torch.Tensor:
+        taps = getattr(self, "_taps", None)   # test hook: a dict set by a parity test receives the residual stream [B*HW, C] bf16 at the block boundaries
         W, cfg, dev = self._w, self.config, self._device
         boc, G, eps = self._boc, cfg.norm_num_groups, cfg.norm_eps
         nlev = len(boc)
@@ -716,6 +717,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                              conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, stride=2), defer_reduce=True)   # -> the next block's norm1
                 hh, ww = ho, wo
                 skips.append((skip_of(x), hh, ww))
+        all_skips = list(skips) if taps is not None else None
         # ---- 4. mid (ref :775-783)
         x = resnet("mid_block.resnets.0.", x, None, hh * ww, hh, ww, "r", gn_next=True)
         x = transformer("mid_block.attentions.0.", x, hh * ww, "r2")
@@ -732,6 +734,8 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                            gn_next=cross or j < L_ or i == nlev - 1)
                 if cross:
                     x = transformer(f"up_blocks.{i}.attentions.{j}.", x, hh * ww, "u" if j % 2 else "ub")
+                    if taps is not None:
+                        taps[f"up{i}.{j}"] = x.clone()
             if i != nlev - 1:
                 ho, wo = skips[-1][1], skips[-1][2]      # = (2 hh, 2 ww) unless a down conv rounded an odd size up
                 x = ops.gemm(x.view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
@@ -744,6 +748,14 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         out = self._buf("eps", (B, cfg.out_channels, h, w), torch.float32)
         ops.gemm(n, W["conv_out"], out, conv=dict(B=B, Hi=h, Wi=w, Ho=h, Wo=w), rows_per_batch=HW,
                  epilogue=ops.EPI_NCHW_F32)
+        if taps is not None:
+            # the down-path skip tensors, read back AFTER the forward: a deferred split-K tensor's buffer is filled by the norm that
+            # consumes it, and every skip buffer stays untouched until here.  Names as oracle.unet.unet_forward's taps.
+            names = ["conv_in"]
+            for i in range(nlev):
+                names += [f"down{i}.{j}" for j in range(L_)] + ([f"ds{i}"] if i != nlev - 1 else [])
+            for nm_, (t_, _, _) in zip(names, all_skips):
+                taps[nm_] = t_.clone()
         return out
 
 

@@ -120,3 +120,84 @@ def test_three_stage_flow(gpu_backend):
     assert rel(out3.latents, o_lat3) <= 6e-2, rel(out3.latents, o_lat3)
     d = (out3.images.cpu().int() - o_u8.int()).abs().float()
     assert out3.images.shape == (1, Himg, 2 * Wimg, 3) and d.mean() <= 3.0, d.mean()
+
+
+FULL_FIXTURE = __import__("pathlib").Path(__file__).resolve().parent / "golden" / "fullsize_three_stage.npz"
+CHAIN_ENC_TOL = 3e-2     # encoder / prior / projection hand-overs (one model each)
+CHAIN_LAT_TOL = 6e-2     # stage-2 / stage-3 latents at the end of the chain (the tiny chain's stated tolerance)
+CHAIN_PIX_TOL = 3.0      # uint8 levels, mean absolute difference
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_three_stage_full_size(gpu_backend):
+    """BASELINE.json configs[3] as a CHAIN at full model sizes (what tools/bench_three_stage.py times), every hand-over compared with
+    the fp32 oracle chain of tests/golden/make_fullsize_three_stage_fixture.py: CLIP-H embedding -> stage-1 prior (1.03 B parameters,
+    20 UnCLIP steps) -> stage-2 class label; DINOv2-giant -> image projection -> stage-2 / stage-3 context; VAE encode of the canvas ->
+    masked latents; stage 2 (N = 2, 10 DDIM steps, hipGraph) -> VAE decode -> target half -> VAE encode -> stage 3 (N = 2, 5 steps) ->
+    VAE decode -> uint8.  Each stage consumes the HIP output of the stage before it (errors accumulate as in production)."""
+    import numpy as np
+    import pcdms_amd as P
+    from tests import three_stage_common as T
+    from tests.parity_record import check as record_check
+    from tests.test_schedulers import SD21
+    from tests.test_unet import _kwargs
+    if not FULL_FIXTURE.exists():
+        pytest.fail(f"{FULL_FIXTURE} missing: run tests/golden/make_fullsize_three_stage_fixture.py")
+    fx = np.load(FULL_FIXTURE)
+    assert str(fx["torch_version"]) == torch.__version__
+    dev = gpu_backend.device
+    Wt, I = T.weights(), T.inputs()
+    rel = lambda a, b: ((a.float().cpu() - torch.as_tensor(np.asarray(b, dtype=np.float32))).norm() / torch.as_tensor(np.asarray(b, dtype=np.float32)).norm()).item()  # noqa: E731
+
+    def load(m, sd):
+        m.load_state_dict(sd)
+        return m.to(dev)
+    clip = load(P.CLIPVisionModelWithProjection(), Wt.pop("clip"))
+    s_embed = clip(I["pix224"].to(dev)).image_embeds.unsqueeze(1)
+    record_check("chain.clip_embed", rel(s_embed, fx["embed"]), CHAIN_ENC_TOL)
+    del clip
+    prior = load(P.Stage1_PriorTransformer(num_embeddings=2, embedding_dim=1024), Wt.pop("prior"))
+    pipe1 = P.Stage1_PriorPipeline(prior).to(dev)
+    pred = pipe1(s_embed=s_embed, s_pose=I["s_kp"].to(dev), t_pose=I["t_kp"].to(dev), num_images_per_prompt=1, num_inference_steps=T.S1_STEPS,
+                 latents=I["s1_lat"].to(dev), guidance_scale=0, variance_noises=I["s1_noise"])[0].unsqueeze(1)
+    record_check("chain.stage1_pred", rel(pred, fx["pred"]), CHAIN_ENC_TOL)
+    del prior, pipe1
+    dino = load(P.Dinov2Model(), Wt.pop("dino"))
+    iproj = load(P.ImageProjModel_p(1536, 768, 1024), Wt.pop("iproj"))
+    feat = iproj(dino(I["pix224"].to(dev)).last_hidden_state)
+    record_check("chain.image_proj", rel(feat, fx["feat"]), CHAIN_ENC_TOL)
+    del dino
+    pose_proj = load(P.ControlNetConditioningEmbedding(320, 3, (16, 32, 96, 256)), Wt.pop("pose"))
+    st_pose_f = pose_proj(I["pose"].to(dev))
+    record_check("chain.pose_embedding", rel(st_pose_f[:, :, ::8, ::8], fx["pose_sub"]), CHAIN_ENC_TOL)
+    vae = load(P.AutoencoderKL(), Wt.pop("vae"))
+
+    class _FixedNoiseVAE:   # vae.encode(...).latent_dist.sample(generator) with the injected posterior noise
+        def __init__(self, noise):
+            self.noise, self.config = noise, vae.config
+            self.decode, self.decode_to_uint8 = vae.decode, vae.decode_to_uint8
+
+        def encode(self, x):
+            d = vae.encode(x).latent_dist
+            n = self.noise
+            return type("E", (), {"latent_dist": type("D", (), {"sample": staticmethod(lambda generator=None: d.sample(noise=n.to(dev)))})})
+    unet2 = load(P.Stage2_InapintUNet2DConditionModel(**_kwargs(Wt["ucfg"])), Wt.pop("unet2"))
+    pipe2 = P.Stage2_InpaintDiffusionPipeline(unet2, P.DDIMScheduler.from_config(SD21), vae=_FixedNoiseVAE(I["post_noise"]))
+    out2 = pipe2(height=T.H, width=2 * T.W, vae_image=I["canvas"].to(dev), s_img_proj_f=feat, st_pose_f=st_pose_f, pred_t_img_embed=pred,
+                 latents=I["s2_lat"].to(dev), num_images_per_prompt=T.N2, guidance_scale=2.0, num_inference_steps=T.S2_STEPS, output_type="pt")
+    assert pipe2._graph is not None
+    record_check("chain.stage2_latents", rel(out2.latents, fx["lat2"]), CHAIN_LAT_TOL)
+    img2_u8 = (out2.images.float().clamp(0, 1) * 255).round().permute(0, 2, 3, 1)[:, ::2, ::2].cpu()
+    d2 = (img2_u8 - torch.from_numpy(fx["img2_u8"]).float()).abs().mean().item()
+    record_check("chain.stage2_pixels", d2, CHAIN_PIX_TOL)
+    gen_t = (out2.images[:1, :, :, T.W:] * 2 - 1).contiguous()            # "pt" output is the denormalised image in [0, 1]
+    del unet2, pipe2
+    unet3 = load(P.UNet2DConditionModel(**_kwargs(Wt["u3cfg"])), Wt.pop("unet3"))
+    pipe3 = P.Stage3_RefinedDiffusionPipeline(unet3, P.DDIMScheduler.from_config(SD21), vae=_FixedNoiseVAE(I["post_noise3"]))
+    out3 = pipe3(height=T.H, width=T.W, vae_gen_t_image=gen_t, s_img_proj_f=feat, latents=I["s3_lat"].to(dev), num_images_per_prompt=T.N3,
+                 guidance_scale=2.0, num_inference_steps=T.S3_STEPS, output_type="uint8")
+    record_check("chain.stage3_latents", rel(out3.latents, fx["lat3"]), CHAIN_LAT_TOL)
+    d3 = (out3.images.cpu().int() - torch.from_numpy(fx["u8"]).int()).abs().float().mean().item()
+    assert out3.images.shape == (T.N3, T.H, T.W, 3)
+    record_check("chain.stage3_pixels", d3, CHAIN_PIX_TOL)
