@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* pcdm_stream_t; /* hipStream_t */
 
-#define PCDM_ABI_VERSION 2   /* what pcdm_version() returns for the library this header belongs to */
+#define PCDM_ABI_VERSION 3   /* what pcdm_version() returns for the library this header belongs to */
 int pcdm_version(void);
 /* 1 only for the test-only CPU lane emulator build (tests/emu); the product .so returns 0. */
 int pcdm_is_emulator(void);
@@ -141,8 +141,16 @@ typedef struct pcdm_gemm_params {
                               but its own time embedding -- the two classifier-free-guidance halves at conv_in and at the first ResnetBlock2D's
                               conv1 (stage2_inpaint_pipeline.py:499-501 doubles the latents; mask, masked latents and pose are shared).  Needs
                               N % 8 == 0, ldo % 8 == 0, rows_per_batch >= 32 and dup_rows % rows_per_batch == 0 with a rowvec; else -1 */
+    const float* ln_row_stats;  /* with ln_wsum on a tiled instance (tiles 2 / 4 / 7 / 8 / 17 / 18 / 26): [M][K / 32][2] fp32 -- per A row and 32-column run
+                                   {sum, sum of squares about the run's own mean}, as left by the launch that produced A with row_stats_out -- the
+                                   kernel merges them into the row's LayerNorm statistics (Chan) instead of taking them in its K loop (NULL: in the
+                                   loop, every N tile again: pays for N <~ 1280 only).  K % 32 == 0 */
+    float* row_stats_out;       /* linear PCDM_EPI_STORE launches on tiles 2 / 4 / 5 / 6 / 7 / 8 / 10 / 18 (else -1): also write those partials of the
+                                   rows stored, [M][N / 32][2] fp32, from the bf16-rounded output values (bias / rowvec / residual included).  The
+                                   producer of the rows a LayerNorm reads next (Transformer2DModel.proj_in, attn1 / attn2 .to_out + residual).
+                                   N % 32 == 0 */
 } pcdm_gemm_params;
-/* pcdm_version() == 2: the struct above ends with defer_reduce, rowvec_step, rowvec_step_stride, dup_rows (1: ended with ln_eps).  Zero-initialise it (memset) and build against
+/* pcdm_version() == 3: the struct above ends with ln_row_stats, row_stats_out (2: ended with dup_rows; 1: with ln_eps).  Zero-initialise it (memset) and build against
  * the header of the library in use: a host compiled against an older header passes a shorter struct.  A host MUST compare
  * pcdm_version() with the PCDM_ABI_VERSION it was compiled against before its first pcdm_gemm call (the library reads the trailing fields
  * unconditionally).  bias, rowvec, ldrv and rowvec_step_stride must keep 16-byte alignment (4 floats): the epilogues load them as

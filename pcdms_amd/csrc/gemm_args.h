@@ -37,6 +37,8 @@ struct GemmArgs {
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
     const float* ln_wsum;    // rowgemm only: the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
     float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
+    const float* ln_row_stats;   // folded LayerNorm, tiled instances (gemm_ext.hip): [M][K / 32][2] partial {sum, M2} of the A rows, written by their producer
+    float* row_stats_out;        // row-statistics producer instances: [M][N / 32][2] partials of the stored rows
     int dup_rows;       // conv, lean epilogue: also write rows m + dup_rows (their own rowvec / residual rows): pcdm_gemm_params.dup_rows
     int defer_reduce;   // split_k > 1: no reduce launch (pcdm_groupnorm_splitk consumes the partial slabs)
     int debug;  // ablation (tools/ablate_gemm.py): bit0 = skip steady-state loads, bit1 = skip MFMAs (staggered tiles only), bit2 = per-workgroup
@@ -58,4 +60,7 @@ __device__ __forceinline__ float gate_act(float g, int act) { return act == PCDM
 // tile ids >= kRowGemmTile0 of pcdm_gemm_params.tile: rowgemm.hip (returns -1 when the problem / epilogue is not one it takes)
 constexpr int kRowGemmTile0 = 31;
 int launch_rowgemm(int tile, const GemmArgs& a, hipStream_t st);
+// gemm_ext.hip: the extended instances of the tiled kernel (gemm_kernel.inc, template EXT): 1 / 2 = folded-LayerNorm consumers (row statistics in
+// the K loop / from the producer's partials), 3 = row-statistics producers.  Returns -1 for a tile id without such an instance.
+int launch_gemm_ext(int ext, int tile, const GemmArgs& a, hipStream_t st);
 }  // namespace pcdm_gemm_detail

@@ -186,7 +186,10 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride
         int64_t rowvec_step_stride = 0;
         int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
+        float* row_stats = nullptr;   // producer: write the LayerNorm partials of the stored rows here when the tile in use can (pcdm_gemm_params.row_stats_out);
+                                      // consumer (gemm_ln): the partials of the A rows (used when stats_valid and the table asks for mode 2)
     };
+    bool stats_valid = false;   // did the last gemm() that was handed G::row_stats write them?
     // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
     pcdm_gn_splitk_src pend;
     const void* pend_out = nullptr;
@@ -235,6 +238,12 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
                 if ((int64_t)p.split_k * M * w->Npad > kSplitKFloats) { p.split_k = 0; p.tile = 0; p.ws = nullptr; p.ws_floats = 0; }
             }
         }
+        if (g.row_stats) {   // (pcdms_amd.ops.gemm(row_stats=): the same condition, so that both schedules launch the same instances)
+            const int tl = p.tile;
+            stats_valid = (tl == 2 || tl == 4 || tl == 5 || tl == 6 || tl == 7 || tl == 8 || tl == 10 || tl == 18) && p.split_k <= 1 && !g.conv &&
+                          g.epilogue == PCDM_EPI_STORE && w->N % 32 == 0;
+            if (stats_valid) p.row_stats_out = g.row_stats;
+        }
         if (pend_out) { rc = -1; u->err = "a deferred split-K reduce was never consumed"; return; }
         if (g.defer && p.split_k > 1 && g.epilogue == PCDM_EPI_STORE && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0) &&
             !getenv_off("PCDM_DEFER_SPLITK")) {
@@ -249,13 +258,19 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         }
         chk(pcdm_gemm(&p, st), "pcdm_gemm");
     }
+    // should the producer of this LayerNorm -> Linear pair's rows write partials?  (pcdms_amd.ops.ln_wants_row_stats with a tuned table)
+    bool ln_wants_stats(int M, const PW* w, const PW* w_ln, int epilogue) const {
+        if (!w || !w_ln || !w_ln->wsum || w->K == 320 || w->K % 32 || getenv_off("PCDM_LN_TILED")) return false;
+        auto it = u->tiles.find(TileKey{1, M, w->Npad, w->K, 0, 0, 0, epilogue, 0, 0, 0});
+        return it != u->tiles.end() && it->second.first > 0 && it->second.second == 2;
+    }
     // LayerNorm -> GEMM: the folded form on the A-in-registers kernel when the table says so, two launches otherwise
     void gemm_ln(const void* a, int64_t lda, int M, const PW* w, const PW* w_ln, const float* gamma, const float* beta, float eps, void* ln_buf,
                  void* out, G g) {
         if (rc || !w) return;
-        if (w_ln && w_ln->wsum) {
+        if (w_ln && w_ln->wsum && (w->K == 320 || !getenv_off("PCDM_LN_TILED"))) {   // (PCDM_LN_TILED=0: levels 1-3 keep their LayerNorm launches: A/B)
             auto it = u->tiles.find(TileKey{1, M, w->Npad, w->K, 0, 0, 0, g.epilogue, 0, 0, 0});
-            if (it != u->tiles.end() && it->second.first >= 31) {
+            if (it != u->tiles.end() && it->second.first > 0) {   // (0 = LayerNorm launch + plain GEMM; 31.. rowgemm.hip; else an LNF instance of gemm.hip)
                 pcdm_gemm_params p;
                 memset(&p, 0, sizeof(p));
                 p.a = a; p.lda = lda; p.c1 = w->K;
@@ -266,6 +281,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
                 p.out = out; p.ldo = g.ldo ? g.ldo : w->N;
                 p.out2 = g.out2; p.ldo2 = g.ldo2;
                 p.ln_wsum = w_ln->wsum; p.ln_eps = eps;
+                if (it->second.second == 2 && g.row_stats && stats_valid) p.ln_row_stats = g.row_stats;   // (mode 2: merge the producer's partials)
                 p.tile = it->second.first;
                 chk(pcdm_gemm(&p, st), "pcdm_gemm (LayerNorm folded)");
                 return;
@@ -366,6 +382,7 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
         }
     }
     for (const char* nm : {"r", "rb", "u", "ub", "r2", "c1", "sc", "t0", "t1", "ln", "q2", "at", "us"}) P.add(nm, act);
+    P.add("rs", act / 8 + kAlign);   // LayerNorm partials: [M][C / 32][2] fp32 = an eighth of an activation's bytes
     P.add("gn", act_gn);
     P.add("ff", act_ff);
     P.add("qk", act_qk);
@@ -692,12 +709,17 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         const int M = B * HW_;
         const std::string b = p + "transformer_blocks.0.";
         R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"));
+        const int64_t r0 = (int64_t)n0 * HW_;
+        float* rs = R.buf<float>("rs");            // LayerNorm partials of the rows in flight: [M][cc / 32][2] (round 5; pcdms_amd/unet.py::transformer)
+        auto twin = [&](const char* nm) -> const PW* { return u->w.count(p + nm) ? &u->w[p + nm] : nullptr; };
         Run::G g0;
+        if (R.ln_wants_stats(M, R.pw(p + "qkv"), twin("qkv_ln"), PCDM_EPI_SPLIT_VT)) g0.row_stats = rs;
         R.gemm(R.buf("gn"), cc, M, R.pw(p + "proj_in"), R.buf("t0"), g0);
         // self-attention
         {
             Run::G g;
             g.rows_per_batch = HW_; g.epilogue = PCDM_EPI_SPLIT_VT; g.out2 = R.buf("vt"); g.ldo2 = lp8(HW_); g.vt_col0 = 2 * cc; g.ldo = 2 * cc;
+            g.row_stats = rs;
             const PW* wl = u->w.count(p + "qkv_ln") ? &u->w[p + "qkv_ln"] : nullptr;
             R.gemm_ln(R.buf("t0"), cc, M, R.pw(p + "qkv"), wl, R.vec(b + "norm1.weight"), R.vec(b + "norm1.bias"), 1e-5f, R.buf("ln"), R.buf("qk"), g);
         }
@@ -713,13 +735,14 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         {
             Run::G g;
             g.residual = R.buf("t0"); g.ldr = cc; g.res_mod = M;
+            if (R.ln_wants_stats(M - (int)r0, R.pw(p + "q2"), twin("q2_ln"), PCDM_EPI_STORE)) g.row_stats = rs;
             R.gemm(R.buf("at"), cc, M, R.pw(p + "o1"), R.buf("t1"), g);
         }
         // cross-attention over the context tokens; the first n0 batch entries have an all-zero context: attn2(x) == to_out.0.bias there
-        const int64_t r0 = (int64_t)n0 * HW_;
         u16 *t1 = R.buf<u16>("t1"), *ln = R.buf<u16>("ln"), *q2 = R.buf<u16>("q2"), *at = R.buf<u16>("at");
         {
             Run::G g;
+            g.row_stats = rs + r0 * (cc / 32) * 2;
             const PW* wl = u->w.count(p + "q2_ln") ? &u->w[p + "q2_ln"] : nullptr;
             R.gemm_ln(t1 + r0 * cc, cc, M - (int)r0, R.pw(p + "q2"), wl, R.vec(b + "norm2.weight"), R.vec(b + "norm2.bias"), 1e-5f, ln + r0 * cc, q2 + r0 * cc, g);
         }
@@ -732,12 +755,14 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         {
             Run::G g;
             g.residual = t1; g.ldr = cc; g.res_mod = M; g.zero_rows = (int)r0;
+            if (R.ln_wants_stats(M, R.pw(p + "ff1"), twin("ff1_ln"), PCDM_EPI_GEGLU)) g.row_stats = rs;
             R.gemm(at, cc, M, R.pw(p + "o2"), R.buf("t0"), g);
         }
         // GEGLU feed-forward
         {
             Run::G g;
             g.epilogue = PCDM_EPI_GEGLU; g.ldo = 4 * cc;
+            g.row_stats = rs;
             const PW* wl = u->w.count(p + "ff1_ln") ? &u->w[p + "ff1_ln"] : nullptr;
             R.gemm_ln(R.buf("t0"), cc, M, R.pw(p + "ff1"), wl, R.vec(b + "norm3.weight"), R.vec(b + "norm3.bias"), 1e-5f, R.buf("ln"), R.buf("ff"), g);
         }

@@ -235,14 +235,15 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
          defer_reduce: Optional[bool] = None, dup_rows: int = 0, rowvec_step: Optional[torch.Tensor] = None,
-         rowvec_step_stride: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
+         rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
     ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  With ``pw_ln`` (the same Linear packed by ``pack_linear_ln`` /
-    ``pack_geglu_ln``: LayerNorm folded into the weights) the A-in-registers kernel (tiles 31..36, K = 320; 34 = four waves, two workgroups per CU: the one in use) needs no LayerNorm pass
-    at all -- it takes the row statistics from the rows it holds; for every other tile the rows go through ``pcdm_layernorm`` into
-    ``ln_buf`` [M, K] first (the tuner times both forms, the LayerNorm launch included, and keeps the faster).
+    ``pack_geglu_ln``: LayerNorm folded into the weights) no LayerNorm pass is needed at all: the A-in-registers kernel (tiles 31..36, K = 320; 34
+    = four waves, two workgroups per CU: the one in use at level 0) takes the row statistics from the rows it holds, the tiled
+    instances of ``LN_TILED_TILES`` (any K: levels 1-3) from the A tiles as they pass through LDS; otherwise the rows go through
+    ``pcdm_layernorm`` into ``ln_buf`` [M, K] first (the tuner times all forms, the LayerNorm launch included, and keeps the fastest).
 
     ``defer_reduce`` (``True``: the reduced tensor is also read by something other than the next GroupNorm -- it gets written by that
     GroupNorm; ``False``-but-not-``None`` i.e. ``0``: only the next GroupNorm reads it): when the configuration in use splits K, skip the
@@ -256,7 +257,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     residual rows (``pcdm_gemm_params.dup_rows``: the CFG-shared prefix of the UNet)."""
     if ln is not None and conv is None and a2 is None and ln_buf is not None:
         return _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0,
-                        tile=tile)
+                        tile=tile, row_stats=row_stats)
     assert ln is None
     p = GemmParams()
     assert a.dtype == BF16 and a.stride(-1) == 1 and (conv is None or a.is_contiguous())
@@ -318,6 +319,14 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     elif split_k > 1:
         split = split_k
     p.tile = tile
+    if row_stats is not None:
+        # producer of LayerNorm partials (pcdm_gemm_params.row_stats_out): [M][N / 32][2] fp32, written by the STORE epilogue of the tiles that
+        # have such an instance; any other configuration leaves the buffer alone and says so (the consumer then takes its own statistics)
+        ok = tile in STATS_TILES and split == 1 and conv is None and epilogue == EPI_STORE and act == ACT_NONE and pw.N % 32 == 0
+        _STATS_VALID[row_stats.untyped_storage().data_ptr()] = ok   # (keyed on the storage: a consumer may read a row slice of the buffer)
+        if ok:
+            assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and row_stats.numel() >= M * (pw.N // 32) * 2
+            p.row_stats_out = _ptr(row_stats)
     deferred = None
     if split > 1:
         ws = _splitk_ws(a.device, split * M * pw.Npad)
@@ -343,16 +352,43 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     return out if deferred is None else deferred
 
 
-def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile):
-    """LayerNorm + GEMM: folded into the A-in-registers kernel when that wins for the shape, two launches otherwise."""
+def row_stats_valid(row_stats: Optional[torch.Tensor]) -> bool:
+    """did the last ``gemm(..., row_stats=buf)`` on this buffer actually write the partials?"""
+    return row_stats is not None and _STATS_VALID.get(row_stats.untyped_storage().data_ptr(), False)
+
+
+def ln_wants_row_stats(M: int, pw: "PackedWeight", epilogue: int) -> bool:
+    """should the producer of the rows of this LayerNorm -> Linear pair write partials (``gemm(..., row_stats=)``)?  Yes when the pair's tuned
+    choice merges partials (mode 2), and while the pair is untuned (the tuner can only measure mode 2 if it is handed partials)."""
+    if not LN_TILED or pw.K == 320 or pw.K % 32:
+        return False
+    ch = _TUNED.get(("ln", M, pw.Npad, pw.K, epilogue))
+    return ch is None or (len(ch) > 1 and ch[0] > 0 and ch[1] == 2)
+
+
+def row_stats_reference(a: torch.Tensor) -> torch.Tensor:
+    """[M][K / 32][2] {sum, M2 about the run's own mean} of every 32-column run of ``a`` (torch; the tuner and the tests)."""
+    M, K = a.shape
+    v = a.float().view(M, K // 32, 32)
+    sm = v.sum(-1)
+    return torch.stack([sm, ((v - sm.unsqueeze(-1) / 32) ** 2).sum(-1)], -1).contiguous()
+
+
+def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile, row_stats=None, mode=None):
+    """LayerNorm + GEMM: folded into the A-in-registers kernel (K = 320) or an extended instance of the tiled kernel when that wins for the
+    shape, two launches otherwise.  Tuned choice per shape = (tile, mode): mode 1 = the kernel takes the row statistics itself, mode 2 = it
+    merges the partials its producer wrote (``row_stats``; falls back to mode 1 on the same tile when the producer could not write them)."""
     gamma, beta, eps = ln
     M = a.shape[0]
     assert a.dtype == BF16 and a.stride(1) == 1 and a.shape[1] == pw.K and ln_buf.shape[0] >= M
     key = ("ln", M, pw.Npad, pw.K, epilogue)
-    choice = tile or _TUNED.get(key)
+    have_stats = row_stats_valid(row_stats)
+    choice = (tile, mode or (2 if have_stats else 1)) if tile else _TUNED.get(key)   # (an explicit tile: partials are used when there are valid ones)
+    if not LN_TILED and not tile and pw.K != 320:   # PCDM_LN_TILED=0: A/B switch -- levels 1-3 keep their LayerNorm launches
+        pw_ln = None
     stream = _stream(a)
 
-    def fused(t):
+    def fused(t, stats=None):
         p = GemmParams()
         p.a, p.lda, p.c1 = _ptr(a), a.stride(0), a.shape[1]
         p.w, p.M, p.N, p.K, p.Npad = _ptr(pw_ln.w), M, pw_ln.N, pw_ln.K, pw_ln.Npad
@@ -364,6 +400,8 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
         if out2 is not None:
             p.out2, p.ldo2 = _ptr(out2), out2.shape[-1]
         p.ln_wsum, p.ln_eps = _ptr(_c(pw_ln.wsum, torch.float32)), float(eps)
+        if stats is not None:
+            p.ln_row_stats = _ptr(stats)
         p.tile = t
         return _lib.lib().pcdm_gemm(C.byref(p), stream)
 
@@ -375,7 +413,7 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
         assert not tile
         two_launches()
         return out
-    if choice is None and AUTOTUNE and a.is_cuda and pw.K == 320 and not torch.cuda.is_current_stream_capturing():
+    if choice is None and AUTOTUNE and a.is_cuda and not torch.cuda.is_current_stream_capturing():
         two_launches()                         # (tunes the plain GEMM of this shape on the way)
         ref = out.float().clone()
 
@@ -388,33 +426,44 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1)
-        best, best_t = 0, timed(two_launches)
-        for t in ROWGEMM_TILES:
-            if fused(t) != 0:
-                continue
-            if not bool(((out.float() - ref).abs().max() <= 3e-2 * ref.abs().max() + 1e-3).item()):
-                continue
-            tt = timed(lambda: fused(t))
-            if tt < best_t:
-                best, best_t = t, tt
-        choice = _TUNED[key] = (best, 1)
+        best, best_t = (0, 1), timed(two_launches)
+        ref_stats = row_stats_reference(a) if (row_stats is not None and pw.K != 320 and pw.K % 32 == 0) else None   # (a caller that has a producer)
+        for t in (ROWGEMM_TILES if pw.K == 320 else ()) + LN_TILED_TILES:
+            for md in (1, 2):
+                st_ = None if md == 1 else ref_stats
+                if (md == 2 and (st_ is None or t in ROWGEMM_TILES)) or fused(t, st_) != 0:   # (the library refuses what a tile cannot do: Npad not a
+                    continue                                                                    #  multiple of its BN, GEGLU on a 32-wide wave tile, ...)
+                if not bool(((out.float() - ref).abs().max() <= 3e-2 * ref.abs().max() + 1e-3).item()):
+                    continue
+                tt = timed(lambda: fused(t, st_))
+                if tt < best_t:
+                    best, best_t = (t, md), tt
+        choice = _TUNED[key] = best
+    md = 1
     if isinstance(choice, tuple):
-        choice = choice[0]
-    if choice:
+        choice, md = choice[0], (choice[1] if len(choice) > 1 else 1)
+    if choice and pw_ln is not None and pw_ln.wsum is not None:
+        stats = row_stats if (md == 2 and have_stats) else None     # (mode 2 without valid partials: the same tile takes its own statistics)
+        fused_ = lambda t: fused(t, stats)  # noqa: E731
         if LAUNCH_LOG is not None and a.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _chk(fused(choice), "pcdm_gemm (LayerNorm folded)")
+            _chk(fused_(choice), "pcdm_gemm (LayerNorm folded)")
             e1.record()
             LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, False, choice, 1), 2.0 * M * pw.alg_nk))
         else:
-            _chk(fused(choice), "pcdm_gemm (LayerNorm folded)")
+            _chk(fused_(choice), "pcdm_gemm (LayerNorm folded)")
         return out
     two_launches()
     return out
 
 
 ROWGEMM_TILES = (31, 32, 33, 34, 35, 36)   # rowgemm.hip (K = 320): id -> (BM, BN) below
+STATS_TILES = (2, 4, 5, 6, 7, 8, 10, 18)   # gemm_ext.hip EXT = 3: the tiles whose STORE epilogue can also write LayerNorm partials (row_stats)
+_STATS_VALID: dict = {}
+LN_TILED = os.environ.get("PCDM_LN_TILED", "1") != "0"
+LN_TILED_TILES = (18, 4, 7, 17, 26, 8, 2)   # gemm.hip dispatch_tile_ln(): the tiled instances that take a folded LayerNorm (any K; row statistics
+#                                             from the A tiles as they pass through LDS) -- levels 1-3 of the UNet, the prior, the encoders
 # gemm.hip dispatch_tile(): id -> (BM, BN)
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),

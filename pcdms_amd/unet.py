@@ -360,7 +360,8 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             a["o2"] = lin(b + "attn2.to_out.0.")
             a["ff1"] = ops.pack_geglu(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"], dev)
             a["ff2"] = lin(b + "ff.net.2.")
-            if c == 320:   # K = 320: the A-in-registers kernel can take these three with their LayerNorm folded into the weights
+            if True:   # second copies of the three LayerNorm-fed linears with the LayerNorm FOLDED into the weights: K = 320 -> the
+                       # A-in-registers kernel (rowgemm.hip); K = 640 / 1280 (round 5) -> the LNF instances of the tiled kernel (gemm.hip)
                 ln = [(sd[b + f"norm{i}.weight"], sd[b + f"norm{i}.bias"]) for i in (1, 2, 3)]
                 a["qkv_ln"] = ops.pack_linear_ln(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"],
                                                             sd[b + "attn1.to_v.weight"]], 0), None, ln[0][0], ln[0][1], dev)
@@ -649,14 +650,20 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
             x = ops.as_tensor(x)
-            t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)))
+            # Row statistics travel with the rows (round 5, levels 1-3): the linear that writes the input of a LayerNorm -- proj_in, attn1.to_out +
+            # residual, attn2.to_out + residual -- also writes the {sum, M2} of every 32-column run (`row_stats`), and the LayerNorm-folded
+            # projection that reads the rows next merges them: no LayerNorm launch, no statistics work in that GEMM's loop (ops._gemm_ln)
+            r0 = nzero * HW_
+            rs = self._buf("rs", (M, c // 32, 2), torch.float32) if c % 32 == 0 else None
+            want = lambda pw_, M_, epi: rs if (rs is not None and pw_ is not None and ops.ln_wants_row_stats(M_, pw_, epi)) else None  # noqa: E731
+            t0 = ops.gemm(n0, a["proj_in"], self._buf("t0", (M, c)), row_stats=want(a.get("qkv_ln"), M, ops.EPI_SPLIT_VT))
             # self-attention
             # LayerNorm -> projection pairs go through ops.gemm(ln=...): at K = 320 (level 0) the A-in-registers kernel takes the weights
             # with the LayerNorm folded in (no LayerNorm launch, no normalised tensor anywhere); elsewhere LayerNorm runs first into "ln"
             qk = self._buf("qk", (M, 2 * c))
             vt = self._buf("vt", (B, c, (HW_ + 7) // 8 * 8), zero=True)
             ops.gemm(t0, a["qkv"], qk, rows_per_batch=HW_, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * c,
-                     ln=(a["ln1"][0], a["ln1"][1], 1e-5), ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("qkv_ln"))
+                     ln=(a["ln1"][0], a["ln1"][1], 1e-5), ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("qkv_ln"), row_stats=rs)
             if self._attn_fp8:
                 HW16 = (HW_ + 15) // 16 * 16
                 k8 = ops.quantize_fp8(qk[:, c:], self._buf("k8", (M, c), ops.FP8))
@@ -664,20 +671,20 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 at = ops.flash_attn_fp8(qk[:, :c], k8, vt8.view(B, c, HW16), self._buf("at", (M, c)), B, H, HW_, HW_)
             else:
                 at = ops.flash_attn(qk[:, :c], qk[:, c:], vt, self._buf("at", (M, c)), B, H, HW_, HW_)
-            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M)
+            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M, row_stats=want(a.get("q2_ln"), M - r0, ops.EPI_STORE))
             # cross-attention over the context tokens; the first n0 batch entries have an all-zero context, for which
             # attn2(x) == to_out.0.bias exactly: their rows skip LN2 / to_q / attention and enter
             # the to_out GEMM as zero A rows (no main loop for tiles that lie entirely inside them)
-            r0 = nzero * HW_
             q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
-                          ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"))
+                          ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"), row_stats=None if rs is None else rs[r0:])
             k2, vt2 = kv[p]
             at2 = self._buf("at", (M, c))
             (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
-            t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0)
+            t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0,
+                          row_stats=want(a.get("ff1_ln"), M, ops.EPI_GEGLU))
             # GEGLU feed-forward
             ff = ops.gemm(t2, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU, ln=(a["ln3"][0], a["ln3"][1], 1e-5),
-                          ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("ff1_ln"))
+                          ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("ff1_ln"), row_stats=rs)
             t3 = ops.gemm(ff, a["ff2"], self._buf("t1", (M, c)), residual=t2, res_mod=M)
             return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M)
 

@@ -15,7 +15,7 @@ ROOT = HERE.parent.parent
 CSRC = ROOT / "pcdms_amd" / "csrc"
 OUT = HERE / "_build"
 LIB = OUT / "libpcdm_emu.so"
-SOURCES = ["norm.hip", "gemm.hip", "rowgemm.hip", "attn.hip", "misc.hip", "unet_ctx.hip"]
+SOURCES = ["norm.hip", "gemm.hip", "gemm_ext.hip", "rowgemm.hip", "attn.hip", "misc.hip", "unet_ctx.hip"]
 
 
 def _cxx() -> str:
@@ -27,7 +27,7 @@ def _cxx() -> str:
 
 def build(force: bool = False) -> Path:
     OUT.mkdir(exist_ok=True)
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "pcdm_device.h", CSRC / "gemm_args.h", ROOT / "include" / "pcdm.h", HERE / "hip_emu.h",
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "pcdm_device.h", CSRC / "gemm_args.h", CSRC / "gemm_kernel.inc", ROOT / "include" / "pcdm.h", HERE / "hip_emu.h",
                                           HERE / "hip_emu.cpp", ROOT / "pcdms_amd" / "tuning" / "gfx950.json"]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB

@@ -52,7 +52,7 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_struct_layouts_match_the_header(tmp_path):
     """The ctypes mirrors in pcdms_amd/_lib.py against the C structs of include/pcdm.h as gcc lays them out: size and the offset of every
     field (pcdm_gemm_params grew without a version bump -- an ABI drift between the header and a binding must fail a test, and
-    ``pcdm_version()`` must say 2 for the struct that ends with ``dup_rows``)."""
+    ``pcdm_version()`` must say 3 for the struct that ends with ``row_stats_out``)."""
     import shutil
     import subprocess
 
@@ -82,4 +82,4 @@ def test_struct_layouts_match_the_header(tmp_path):
     body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct pcdm_gemm_params {"):hdr.index("} pcdm_gemm_params;")], flags=re.S)
     names = re.findall(r"(\w+)\s*(?:,|;)", body.split("{", 1)[1])
     assert names == [f for f, _ in _lib.GemmParams._fields_], (names, [f for f, _ in _lib.GemmParams._fields_])
-    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 2
+    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 3

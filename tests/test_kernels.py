@@ -819,6 +819,121 @@ def test_rowgemm_folded_layernorm_large_mean(backend):
         close(out, ref)
 
 
+def test_gemm_folded_layernorm_tiled(backend):
+    """The LNF instances of the tiled GEMM (gemm.hip ``dispatch_tile_ln``; round 5): LayerNorm folded into the weights, the row statistics
+    taken inside the kernel from the A tiles as they pass through LDS (shifted sums) -- the K = 640 / 1280 linears of UNet levels 1-3.
+    All three epilogues (store, GEGLU, q | k | v^T) on every instance, ragged M, rows with |mean| = 30 std mixed in; reference:
+    LayerNorm (fp64) -> GEMM (fp64) on the same bf16 rows."""
+    dev = backend.device
+    g = torch.Generator().manual_seed(290)
+    for K, M, N in ([(128, 200, 256), (192, 96, 256)] if backend.is_emu else [(640, 11264, 1920), (1280, 2816 - 24, 1280), (1280, 704, 3840)]):
+        gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+        a = torch.randn(M, K, generator=g) * (torch.rand(M, 1, generator=g) * 3 + 0.2)
+        a[::7] += 30.0 * a[::7].std(-1, keepdim=True)                    # rows whose |mean| >> std
+        a = a.to(BF16)
+        ln64 = F.layer_norm(a.double(), (K,), gamma.double(), beta.double(), 1e-5)
+        # ---- store
+        w = rnd(N, K, seed=291, scale=1 / math.sqrt(K))
+        bias = torch.randn(N, generator=g)
+        pw = ops.pack_linear(w.float(), bias, dev)
+        pw_ln = ops.pack_linear_ln(w.float(), bias, gamma, beta, dev)
+        ref = ln64 @ w.double().t() + bias.double()
+        for tile in ops.LN_TILED_TILES:
+            if pw.Npad % ops.TILE_SHAPES[tile][1]:
+                continue
+            out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(a.to(dev), pw, out, tile=tile, ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, K, dtype=BF16, device=dev), pw_ln=pw_ln)
+            backend.sync()
+            close(out, ref)
+        # ---- GEGLU (64-wide wave tiles)
+        D = N // 2
+        wg = rnd(2 * D, K, seed=292, scale=1 / math.sqrt(K))
+        bg = torch.randn(2 * D, generator=g) * 0.5
+        pg, pg_ln = ops.pack_geglu(wg.float(), bg, dev), ops.pack_geglu_ln(wg.float(), bg, gamma, beta, dev)
+        h, gt = (ln64 @ wg.double().t() + bg.double()).chunk(2, -1)
+        for tile in (18, 4, 7, 17, 26):
+            if pg.Npad % ops.TILE_SHAPES[tile][1]:
+                continue
+            out = torch.full((M, D), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(a.to(dev), pg, out, epilogue=ops.EPI_GEGLU, tile=tile, ln=(gamma.to(dev), beta.to(dev), 1e-5),
+                     ln_buf=torch.empty(M, K, dtype=BF16, device=dev), pw_ln=pg_ln)
+            backend.sync()
+            close(out, h * F.gelu(gt))
+        # ---- q | k | v^T: tokens per batch entry a multiple of 32, M a multiple of 32
+        Bq = 2
+        T = (M // Bq) // 32 * 32
+        Mq, Cc = Bq * T, 128 if backend.is_emu else N // 3 // 64 * 64
+        pr = ln64[:Mq] @ rnd(3 * Cc, K, seed=293, scale=1 / math.sqrt(K)).double().t()
+        wq = rnd(3 * Cc, K, seed=293, scale=1 / math.sqrt(K))
+        pq, pq_ln = ops.pack_linear(wq.float(), None, dev), ops.pack_linear_ln(wq.float(), None, gamma, beta, dev)
+        for tile in (18, 26, 2):
+            if pq.Npad % ops.TILE_SHAPES[tile][1]:
+                continue
+            qk = torch.full((Mq, 2 * Cc), float("nan"), dtype=BF16, device=dev)
+            vt = torch.zeros(Bq, Cc, T + 8, dtype=BF16, device=dev)
+            ops.gemm(a[:Mq].to(dev), pq, qk, rows_per_batch=T, epilogue=ops.EPI_SPLIT_VT, out2=vt, vt_col0=2 * Cc, tile=tile,
+                     ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(Mq, K, dtype=BF16, device=dev), pw_ln=pq_ln)
+            backend.sync()
+            close(qk, pr[:, : 2 * Cc])
+            close(vt[:, :, :T], pr[:, 2 * Cc:].view(Bq, T, Cc).permute(0, 2, 1))
+    # what the instances do not implement is refused, not silently mis-computed
+    with pytest.raises(RuntimeError):
+        ops.gemm(a.to(dev), pw, torch.empty(M, N, dtype=BF16, device=dev), tile=21, ln=(gamma.to(dev), beta.to(dev), 1e-5),
+                 ln_buf=torch.empty(M, K, dtype=BF16, device=dev), pw_ln=pw_ln)
+
+
+def test_gemm_row_stats_producer_and_consumer(backend):
+    """Round 5: the LayerNorm statistics of a row travel from the linear that WRITES the row to the linear that reads it.  Producer
+    (gemm_ext.hip EXT = 3, ``row_stats=``): a STORE launch with bias + residual also leaves {sum, M2} of every 32-column run of the
+    bf16 values it stores -- compared element for element with the same quantities taken from its output tensor; consumer (EXT = 2):
+    the folded-LayerNorm GEMM merges them (Chan) instead of taking statistics in its K loop -- against LayerNorm (fp64) -> GEMM
+    (fp64) of the stored rows, and against the in-loop form (EXT = 1) of the same tile."""
+    dev = backend.device
+    g = torch.Generator().manual_seed(390)
+    for (M, K0, C, N) in ([(200, 64, 128, 256)] if backend.is_emu else [(11264, 640, 640, 1920), (2816 - 24, 1280, 1280, 1280)]):
+        x = rnd(M, K0, seed=391)
+        res = (torch.randn(M, C, generator=g) * 2 + 8.0 * torch.randn(M, 1, generator=g)).to(BF16)   # rows with a large common offset
+        w0 = rnd(C, K0, seed=392, scale=1 / math.sqrt(K0))
+        b0 = torch.randn(C, generator=g)
+        pw0 = ops.pack_linear(w0.float(), b0, dev)
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        w1 = rnd(N, C, seed=393, scale=1 / math.sqrt(C))
+        b1 = torch.randn(N, generator=g)
+        pw1, pw1_ln = ops.pack_linear(w1.float(), b1, dev), ops.pack_linear_ln(w1.float(), b1, gamma, beta, dev)
+        for ptile in ops.STATS_TILES:
+            if pw0.Npad % ops.TILE_SHAPES[ptile][1]:
+                continue
+            t = torch.full((M, C), float("nan"), dtype=BF16, device=dev)
+            stats = torch.full((M, C // 32, 2), float("nan"), dtype=torch.float32, device=dev)
+            ops.gemm(x.to(dev), pw0, t, residual=res.to(dev), res_mod=M, tile=ptile, row_stats=stats)
+            backend.sync()
+            assert ops.row_stats_valid(stats), ptile
+            close(t, x.float() @ w0.float().t() + b0 + res.float())
+            want = ops.row_stats_reference(t.cpu())
+            got = stats.cpu()
+            assert torch.isfinite(got).all(), ptile
+            assert (got[..., 0] - want[..., 0]).abs().max() <= 1e-4 * want[..., 0].abs().max() + 1e-4, ptile
+            assert (got[..., 1] - want[..., 1]).abs().max() <= 1e-3 * want[..., 1].abs().max() + 1e-3, ptile
+        # ---- consumer on the last producer's tensor + partials
+        ref = F.layer_norm(t.cpu().double(), (C,), gamma.double(), beta.double(), 1e-5) @ w1.double().t() + b1.double()
+        for ctile in (18, 4, 7, 8, 2, 17, 26):
+            if pw1.Npad % ops.TILE_SHAPES[ctile][1]:
+                continue
+            outs = []
+            for st in (stats, None):
+                out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+                ops.gemm(t, pw1, out, tile=ctile, ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, C, dtype=BF16, device=dev),
+                         pw_ln=pw1_ln, row_stats=st)
+                backend.sync()
+                close(out, ref)
+                outs.append(out.float().cpu())
+            assert (outs[0] - outs[1]).abs().max() <= 2e-2 * ref.abs().max(), ctile     # partials vs in-loop statistics: same numbers, other order
+    # a configuration without a producer instance leaves the buffer alone and says so
+    st2 = torch.zeros(M, C // 32, 2, dtype=torch.float32, device=dev)
+    ops.gemm(x.to(dev), pw0, t, tile=21 if pw0.Npad % 320 == 0 else 1, row_stats=st2) if pw0.Npad % 128 == 0 else None
+    assert not ops.row_stats_valid(st2)
+
+
 def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:
     bits = torch.arange(0, 1 << 16, dtype=torch.int32)
     v = bits.to(torch.int16).view(BF16)

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--flops", default="", help="JSON of tools/profile_step.py --flops-json: algorithmic FLOPs of one step per family")
     a = ap.parse_args()
     f = glob.glob(a.dir + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
@@ -53,6 +54,30 @@ def main():
             fam[key][1] += t
     for k, (c, t) in fam.items():
         print(f"{k:72s} {c / n:8.1f} {t / c / 1e3:9.2f} {t / n / 1e6:8.3f} {100 * t / busy:6.1f}")
+    # FLOP-weighted TF/s per family: conv3x3 = the CONV instantiations of gemm_kernel (6th template argument), Linear = the
+    # other gemm_kernel instantiations + rowgemm_kernel, attention = flash_attn*; FLOPs = the un-padded algorithmic 2 M N K / 4 B H Lq Lk 64
+    # of one step (tools/profile_step.py), time = this trace's kernel durations
+    if a.flops:
+        import json
+        fl = json.load(open(a.flops))
+        t_f = defaultdict(lambda: [0, 0])
+        for k, (c, t) in agg.items():
+            if k.startswith("gemm_kernel"):
+                args_ = k[k.index("<") + 1:].split(",")
+                key = "conv3x3" if len(args_) > 5 and args_[5].strip() == "true" else "linear"
+            elif k.startswith("rowgemm_kernel"):
+                key = "linear"
+            elif "flash_attn" in k:
+                key = "attention"
+            else:
+                continue
+            t_f[key][0] += c
+            t_f[key][1] += t
+        for key in ("conv3x3", "linear", "attention"):
+            if key in fl and t_f[key][1]:
+                ms = t_f[key][1] / n / 1e6
+                print(f"# family {key:10s}: {t_f[key][0] / n:6.1f} launches, {ms:7.3f} ms per step, {fl[key]['flops'] / 1e12:6.3f} TFLOP per step => "
+                      f"{fl[key]['flops'] / (ms * 1e-3) / 1e12:7.1f} TF/s FLOP-weighted ({fl[key]['flops'] / (ms * 1e-3) / 2.5e15:.3f} of the 2.5 PF/s roof)")
 
 
 if __name__ == "__main__":

@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--flops-json", default="", help="write the algorithmic FLOPs of one step per family (conv3x3 / Linear / attention) here: "
+                    "tools/kernel_trace_summary.py --flops turns the rocprofv3 family times into FLOP-weighted TF/s")
     args = ap.parse_args()
     from oracle.pipeline import synth_inputs
     from oracle.unet import UNetConfig, synth_state_dict
@@ -57,10 +59,22 @@ def main():
         agg[k][1] += flops
         agg[k][2] += a.elapsed_time(b) * 1e-3
     tot = sum(v[2] for v in agg.values())
+    fam = defaultdict(lambda: [0, 0.0, 0.0])
+    for (name, info), (n, fl, t) in agg.items():
+        f = "attention" if name.startswith("flash_attn") else ("conv3x3" if name == "gemm_kernel" and info[3] else ("linear" if name == "gemm_kernel" else None))
+        if f:
+            fam[f][0] += n
+            fam[f][1] += fl
+            fam[f][2] += t
+    if args.flops_json:
+        import json
+        Path(args.flops_json).write_text(json.dumps({k: {"launches": v[0], "flops": v[1], "event_ms": v[2] * 1e3} for k, v in fam.items()}, indent=1))
     print(f"eager step wall {e0.elapsed_time(e1):.2f} ms; timed launches (GEMM / attention / GroupNorm / LayerNorm) {tot*1e3:.2f} ms in {len(log)} launches")
     print(f"{'kernel':18s} {'shape (M,N,K,conv,tile) / (B,H,Lq,Lk)':46s} {'n':>3s} {'ms':>8s} {'%':>6s} {'TF/s|TB/s':>10s}")
     for (name, info), (n, fl, t) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
         print(f"{name:18s} {str(info):46s} {n:3d} {t*1e3:8.3f} {100*t/tot:6.1f} {fl/t/1e12:10.2f}")
+    for k, (n, fl, t) in sorted(fam.items()):
+        print(f"# family {k:10s}: {n:3d} launches, {fl / 1e12:6.3f} TFLOP, {t * 1e3:7.3f} ms (HIP events) => {fl / t / 1e12:7.1f} TF/s FLOP-weighted")
 
 
 if __name__ == "__main__":
