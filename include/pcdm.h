@@ -144,7 +144,7 @@ typedef struct pcdm_gemm_params {
     const float* ln_row_stats;  /* with ln_wsum on a tiled instance (tiles 2 / 4 / 7 / 8 / 17 / 18 / 26): [M][K / 32][2] fp32 -- per A row and 32-column run
                                    {sum, sum of squares about the run's own mean}, as left by the launch that produced A with row_stats_out -- the
                                    kernel merges them into the row's LayerNorm statistics (Chan) instead of taking them in its K loop (NULL: in the
-                                   loop, every N tile again: pays for N <~ 1280 only).  K % 32 == 0 */
+                                   loop, every N tile again: pays for N <~ 1280 only).  K % 64 == 0, K <= 1280, 16-byte aligned */
     float* row_stats_out;       /* linear PCDM_EPI_STORE launches on tiles 2 / 4 / 5 / 6 / 7 / 8 / 10 / 18 (else -1): also write those partials of the
                                    rows stored, [M][N / 32][2] fp32, from the bf16-rounded output values (bias / rowvec / residual included).  The
                                    producer of the rows a LayerNorm reads next (Transformer2DModel.proj_in, attn1 / attn2 .to_out + residual).
@@ -172,6 +172,15 @@ int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, cons
 #define PCDM_ATTN_DEFAULT_THR 8.0f
 int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                         void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s);
+
+/* The cross-attention of a BasicTransformerBlock with its query path inside (norm2 -> attn2.to_q -> attention over the context tokens;
+ * /root/reference/src/models/stage2_inpaint_unet_2d_condition.py:321-361 -> diffusers BasicTransformerBlock.attn2): x [B*Lq, ldx] bf16 = the
+ * block's token rows (C channels, C % 64 == 0), wq [H*64][C] bf16 + wq_bias / wq_wsum [H*64] fp32 = to_q with the LayerNorm folded in (as
+ * pcdm_gemm_params.ln_wsum; wq_wsum NULL: plain projection).  Each workgroup projects its own 128 x 64 query tile (row statistics from the
+ * rows it loads), rounds it to bf16 where pcdm_gemm would have stored it, and runs pcdm_flash_attn's loop.  One launch for three. */
+int pcdm_flash_attn_qproj(const void* x, int64_t ldx, int C, const void* wq, const float* wq_bias, const float* wq_wsum, float ln_eps,
+                          const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Lq, int Lk,
+                          float scale, pcdm_stream_t s);
 
 /* ---- N4 (BASELINE.json configs[4]): the same attention with OCP e4m3 operands on the MX-scaled fp8 MFMA (unit block
  *      scales; twice the bf16 matrix rate).  No reference counterpart (attention enters at stage2_batchtest_inpaint_model.py:133).

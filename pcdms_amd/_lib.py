@@ -75,6 +75,7 @@ _SIGS = {
     "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),
     "pcdm_flash_attn": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_flash_attn_thr": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _P], C.c_int),
+    "pcdm_flash_attn_qproj": ([_P, _L, _I, _P, _P, _P, _F, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_quantize_fp8": ([_P, _P, _L, _I, _I, _L, _L, _F, _P], C.c_int),
     "pcdm_flash_attn_fp8": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _F, _F, _P], C.c_int),
     "pcdm_timestep_embedding": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),

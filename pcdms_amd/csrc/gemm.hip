@@ -179,7 +179,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         if (p->epilogue == PCDM_EPI_SPLIT_VT && (p->vt_col0 % 64 || p->rows_per_batch % 32 || (p->ldo2 & 7) || p->M % 32)) return -1;
         if (p->epilogue == PCDM_EPI_GEGLU && (tile == 2 || tile == 8)) return -1;   // (GEGLU pairs need a 64-wide wave tile)
         if (((tile == 4 || tile == 7 || tile == 18) && p->Npad % 128) || ((tile == 17 || tile == 26) && p->Npad % 256)) return -1;
-        if (a.ln_row_stats && ((p->K & 31) || ((uintptr_t)a.ln_row_stats & 7))) return -1;
+        if (a.ln_row_stats && ((p->K & 63) || p->K > 1280 || ((uintptr_t)a.ln_row_stats & 15))) return -1;   // (16-byte loads of pair couples; <= 40 pairs per row)
         return pcdm_gemm_detail::launch_gemm_ext(a.ln_row_stats ? 2 : 1, tile, a, st);
     }
     if (a.ln_row_stats) return -1;

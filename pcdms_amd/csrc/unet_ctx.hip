@@ -260,7 +260,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
     }
     // should the producer of this LayerNorm -> Linear pair's rows write partials?  (pcdms_amd.ops.ln_wants_row_stats with a tuned table)
     bool ln_wants_stats(int M, const PW* w, const PW* w_ln, int epilogue) const {
-        if (!w || !w_ln || !w_ln->wsum || w->K == 320 || w->K % 32 || getenv_off("PCDM_LN_TILED")) return false;
+        if (!w || !w_ln || !w_ln->wsum || w->K == 320 || w->K % 64 || w->K > 1280 || getenv_off("PCDM_LN_TILED")) return false;
         auto it = u->tiles.find(TileKey{1, M, w->Npad, w->K, 0, 0, 0, epilogue, 0, 0, 0});
         return it != u->tiles.end() && it->second.first > 0 && it->second.second == 2;
     }
@@ -712,6 +712,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         const int64_t r0 = (int64_t)n0 * HW_;
         float* rs = R.buf<float>("rs");            // LayerNorm partials of the rows in flight: [M][cc / 32][2] (round 5; pcdms_amd/unet.py::transformer)
         auto twin = [&](const char* nm) -> const PW* { return u->w.count(p + nm) ? &u->w[p + nm] : nullptr; };
+        const bool xq = !getenv_off("PCDM_XATTN_QPROJ") && !u->attn_fp8 && twin("q2_ln") && twin("q2_ln")->wsum;
         Run::G g0;
         if (R.ln_wants_stats(M, R.pw(p + "qkv"), twin("qkv_ln"), PCDM_EPI_SPLIT_VT)) g0.row_stats = rs;
         R.gemm(R.buf("gn"), cc, M, R.pw(p + "proj_in"), R.buf("t0"), g0);
@@ -735,19 +736,24 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         {
             Run::G g;
             g.residual = R.buf("t0"); g.ldr = cc; g.res_mod = M;
-            if (R.ln_wants_stats(M - (int)r0, R.pw(p + "q2"), twin("q2_ln"), PCDM_EPI_STORE)) g.row_stats = rs;
+            if (!xq && R.ln_wants_stats(M - (int)r0, R.pw(p + "q2"), twin("q2_ln"), PCDM_EPI_STORE)) g.row_stats = rs;
             R.gemm(R.buf("at"), cc, M, R.pw(p + "o1"), R.buf("t1"), g);
         }
         // cross-attention over the context tokens; the first n0 batch entries have an all-zero context: attn2(x) == to_out.0.bias there
         u16 *t1 = R.buf<u16>("t1"), *ln = R.buf<u16>("ln"), *q2 = R.buf<u16>("q2"), *at = R.buf<u16>("at");
-        {
+        if (xq) {   // LayerNorm2 -> to_q inside the attention kernel (pcdms_amd/unet.py::transformer, ops.flash_attn_qproj)
+            const PW* wl = twin("q2_ln");
+            R.chk(pcdm_flash_attn_qproj(t1 + r0 * cc, cc, cc, wl->w, wl->bias, wl->wsum, 1e-5f, R.buf("k2:" + p), cc, R.buf("vt2:" + p), lp8(L), at + r0 * cc, cc,
+                                        B - n0, H, HW_, L, 0.125f, s), "pcdm_flash_attn_qproj");
+        } else {
             Run::G g;
             g.row_stats = rs + r0 * (cc / 32) * 2;
             const PW* wl = u->w.count(p + "q2_ln") ? &u->w[p + "q2_ln"] : nullptr;
             R.gemm_ln(t1 + r0 * cc, cc, M - (int)r0, R.pw(p + "q2"), wl, R.vec(b + "norm2.weight"), R.vec(b + "norm2.bias"), 1e-5f, ln + r0 * cc, q2 + r0 * cc, g);
         }
         if (R.rc) return nullptr;
-        if (u->attn_fp8)
+        if (xq) {
+        } else if (u->attn_fp8)
             R.chk(pcdm_flash_attn_fp8(q2 + r0 * cc, cc, R.buf("k2_8:" + p), cc, R.buf("vt2_8:" + p), lp16(L), at + r0 * cc, cc, B - n0, H, HW_, L, 0.125f, 1.0f,
                                       1.0f, 5.0f, s), "pcdm_flash_attn_fp8");
         else

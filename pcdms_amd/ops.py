@@ -360,7 +360,7 @@ def row_stats_valid(row_stats: Optional[torch.Tensor]) -> bool:
 def ln_wants_row_stats(M: int, pw: "PackedWeight", epilogue: int) -> bool:
     """should the producer of the rows of this LayerNorm -> Linear pair write partials (``gemm(..., row_stats=)``)?  Yes when the pair's tuned
     choice merges partials (mode 2), and while the pair is untuned (the tuner can only measure mode 2 if it is handed partials)."""
-    if not LN_TILED or pw.K == 320 or pw.K % 32:
+    if not LN_TILED or pw.K == 320 or pw.K % 64 or pw.K > 1280:
         return False
     ch = _TUNED.get(("ln", M, pw.Npad, pw.K, epilogue))
     return ch is None or (len(ch) > 1 and ch[0] > 0 and ch[1] == 2)
@@ -427,7 +427,7 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
             e1.synchronize()
             return e0.elapsed_time(e1)
         best, best_t = (0, 1), timed(two_launches)
-        ref_stats = row_stats_reference(a) if (row_stats is not None and pw.K != 320 and pw.K % 32 == 0) else None   # (a caller that has a producer)
+        ref_stats = row_stats_reference(a) if (row_stats is not None and pw.K != 320 and pw.K % 64 == 0 and pw.K <= 1280) else None   # (a caller that has a producer)
         for t in (ROWGEMM_TILES if pw.K == 320 else ()) + LN_TILED_TILES:
             for md in (1, 2):
                 st_ = None if md == 1 else ref_stats
@@ -618,6 +618,33 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
     if log:
         e1.record()
         LAUNCH_LOG.append(("flash_attn_kernel", 4.0 * B * H * Lq * Lk * 64, e0, e1, (B, H, Lq, Lk)))
+    return out
+
+
+XATTN_QPROJ = os.environ.get("PCDM_XATTN_QPROJ", "1") != "0"   # A/B switch: the cross-attention's query projection inside the attention kernel
+
+
+def flash_attn_qproj(x: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,
+                     Lk: int, ln_eps: float = 1e-5, scale: Optional[float] = None) -> torch.Tensor:
+    """Cross-attention with ``LayerNorm -> to_q`` inside the attention kernel (pcdm_flash_attn_qproj): ``x`` [B*Lq, C] token rows, ``pw_q`` the
+    to_q weight packed by ``pack_linear_ln`` (LayerNorm folded; ``wsum`` None = plain projection, no LayerNorm).  The projection's FLOPs are
+    logged with the attention launch (same algorithmic total as the two launches it replaces)."""
+    for t in (x, k, vt, out):
+        assert t.dtype == BF16
+    C_ = pw_q.K
+    assert x.stride(1) == 1 and x.shape[1] == C_ and pw_q.N == H * 64 and k.stride(1) == 1 and vt.is_contiguous() and out.stride(1) == 1
+    scale = scale if scale is not None else 1.0 / math.sqrt(64)
+    log = LAUNCH_LOG is not None and x.is_cuda
+    if log:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().pcdm_flash_attn_qproj(_ptr(x), x.stride(0), C_, _ptr(pw_q.w), _ptr(pw_q.bias) if pw_q.bias is not None else None,
+                                         _ptr(_c(pw_q.wsum, torch.float32)) if pw_q.wsum is not None else None, float(ln_eps),
+                                         _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out), out.stride(0), B, H, Lq, Lk, scale, _stream(x))
+    _chk(rc, "pcdm_flash_attn_qproj")
+    if log:
+        e1.record()
+        LAUNCH_LOG.append(("flash_attn_kernel", 4.0 * B * H * Lq * Lk * 64 + 2.0 * B * Lq * C_ * (H * 64), e0, e1, (B, H, Lq, Lk, "qproj")))
     return out
 
 

@@ -671,15 +671,21 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 at = ops.flash_attn_fp8(qk[:, :c], k8, vt8.view(B, c, HW16), self._buf("at", (M, c)), B, H, HW_, HW_)
             else:
                 at = ops.flash_attn(qk[:, :c], qk[:, c:], vt, self._buf("at", (M, c)), B, H, HW_, HW_)
-            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M, row_stats=want(a.get("q2_ln"), M - r0, ops.EPI_STORE))
+            # round 5: LayerNorm2 -> to_q runs INSIDE the cross-attention kernel (ops.flash_attn_qproj: one launch instead of two or three)
+            xq = ops.XATTN_QPROJ and not self._attn_fp8 and a.get("q2_ln") is not None
+            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M,
+                          row_stats=None if xq else want(a.get("q2_ln"), M - r0, ops.EPI_STORE))
             # cross-attention over the context tokens; the first n0 batch entries have an all-zero context, for which
             # attn2(x) == to_out.0.bias exactly: their rows skip LN2 / to_q / attention and enter
             # the to_out GEMM as zero A rows (no main loop for tiles that lie entirely inside them)
-            q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
-                          ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"), row_stats=None if rs is None else rs[r0:])
             k2, vt2 = kv[p]
             at2 = self._buf("at", (M, c))
-            (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
+            if xq:
+                ops.flash_attn_qproj(t1[r0:], a["q2_ln"], k2, vt2, at2[r0:], B - nzero, H, HW_, L, ln_eps=1e-5)
+            else:
+                q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
+                              ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"), row_stats=None if rs is None else rs[r0:])
+                (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
             t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0,
                           row_stats=want(a.get("ff1_ln"), M, ops.EPI_GEGLU))
             # GEGLU feed-forward

@@ -479,6 +479,49 @@ def test_flash_attn(backend, case):
         close(o2, ref, tol=1.5e-2)
 
 
+@pytest.mark.parametrize("case", ["level0", "level1", "level2", "plain"])
+def test_flash_attn_qproj(backend, case):
+    """Cross-attention with ``LayerNorm -> to_q`` inside the attention kernel (round 5, pcdm_flash_attn_qproj): against the composition it
+    replaces computed in fp64 / fp32 -- LayerNorm(x) W_q^T rounded to bf16, then softmax attention over the 258 context tokens -- and
+    against the library's own unfused path (folded-LayerNorm GEMM -> pcdm_flash_attn).  Ragged query counts, rows with a large common
+    offset (the shifted row sums), the three channel widths of the UNet; ``plain``: no LayerNorm (wsum = NULL)."""
+    dev = backend.device
+    if backend.is_emu:
+        B, H, Lq, Lk = {"level0": (1, 1, 40, 66), "level1": (2, 2, 33, 70), "level2": (1, 3, 24, 20), "plain": (1, 2, 70, 66)}[case]
+    else:
+        B, H, Lq, Lk = {"level0": (4, 5, 5632, 258), "level1": (4, 10, 1408, 258), "level2": (4, 20, 352 - 5, 258), "plain": (2, 10, 1000, 258)}[case]
+    C = H * 64
+    g = torch.Generator().manual_seed(470)
+    x = torch.randn(B * Lq, C, generator=g) * (torch.rand(B * Lq, 1, generator=g) * 2 + 0.3)
+    x[::5] += 10.0                                                     # rows whose |mean| >> std
+    x = x.to(BF16)
+    wq = rnd(C, C, seed=471, scale=1 / math.sqrt(C))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+    k, v = rnd(B * Lk, C, seed=472), rnd(B * Lk, C, seed=473)
+    Lp = (Lk + 7) // 8 * 8
+    vt = torch.zeros(B, C, Lp, dtype=BF16)
+    vt[:, :, :Lk] = v.view(B, Lk, C).permute(0, 2, 1)
+    if case == "plain":
+        pw_q = ops.pack_linear(wq.float(), None, dev)
+        qref = (x.double() @ wq.double().t()).to(BF16)
+    else:
+        pw_q = ops.pack_linear_ln(wq.float(), None, gamma, beta, dev)
+        qref = (F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5) @ wq.double().t()).to(BF16)
+    out = torch.full((B * Lq, C), float("nan"), dtype=BF16, device=dev)
+    ops.flash_attn_qproj(x.to(dev), pw_q, k.to(dev), vt.to(dev), out, B, H, Lq, Lk)
+    backend.sync()
+    ref = _attn_ref(qref, k, v, B, H, Lq, Lk)
+    close(out, ref, tol=1.5e-2)
+    if case != "plain":   # the unfused path of the library on the same operands
+        q2 = torch.empty(B * Lq, C, dtype=BF16, device=dev)
+        ops.gemm(x.to(dev), ops.pack_linear(wq.float(), None, dev), q2, ln=(gamma.to(dev), beta.to(dev), 1e-5),
+                 ln_buf=torch.empty(B * Lq, C, dtype=BF16, device=dev), pw_ln=None)
+        o2 = torch.empty_like(out)
+        ops.flash_attn(q2, k.to(dev), vt.to(dev), o2, B, H, Lq, Lk)
+        backend.sync()
+        close(out, o2.float(), tol=1.5e-2)
+
+
 def _e4m3(x: torch.Tensor) -> torch.Tensor:
     """OCP e4m3fn round trip (RNE, saturating) -- torch's own float8_e4m3fn cast, used only as the test's quantiser."""
     return x.float().clamp(-448, 448).to(torch.float8_e4m3fn).float()
