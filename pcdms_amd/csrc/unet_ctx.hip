@@ -283,8 +283,11 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
                 p.ln_wsum = w_ln->wsum; p.ln_eps = eps;
                 if (it->second.second == 2 && g.row_stats && stats_valid) p.ln_row_stats = g.row_stats;   // (mode 2: merge the producer's partials)
                 p.tile = it->second.first;
-                chk(pcdm_gemm(&p, st), "pcdm_gemm (LayerNorm folded)");
-                return;
+                const int rc_ = pcdm_gemm(&p, st);
+                if (rc_ != -1) {   // (-1: refused before any launch -- e.g. 88 tokens per image for the V^T pass of a key tuned at 352: two launches,
+                    chk(rc_, "pcdm_gemm (LayerNorm folded)");   //  as pcdms_amd.ops._gemm_ln does)
+                    return;
+                }
             }
         }
         chk(pcdm_layernorm(a, ln_buf, M, w->K, eps, gamma, beta, st), "pcdm_layernorm");
@@ -712,7 +715,9 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         const int64_t r0 = (int64_t)n0 * HW_;
         float* rs = R.buf<float>("rs");            // LayerNorm partials of the rows in flight: [M][cc / 32][2] (round 5; pcdms_amd/unet.py::transformer)
         auto twin = [&](const char* nm) -> const PW* { return u->w.count(p + nm) ? &u->w[p + nm] : nullptr; };
-        const bool xq = !getenv_off("PCDM_XATTN_QPROJ") && !u->attn_fp8 && twin("q2_ln") && twin("q2_ln")->wsum;
+        // (opt-in, PCDM_XATTN_QPROJ=1: measured slower than the launches it replaces, profiles/r5_bench_xattn.txt)
+        const char* xq_env = getenv("PCDM_XATTN_QPROJ");
+        const bool xq = xq_env && xq_env[0] == '1' && !u->attn_fp8 && twin("q2_ln") && twin("q2_ln")->wsum;
         Run::G g0;
         if (R.ln_wants_stats(M, R.pw(p + "qkv"), twin("qkv_ln"), PCDM_EPI_SPLIT_VT)) g0.row_stats = rs;
         R.gemm(R.buf("gn"), cc, M, R.pw(p + "proj_in"), R.buf("t0"), g0);

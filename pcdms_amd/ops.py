@@ -445,14 +445,21 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
     if choice and pw_ln is not None and pw_ln.wsum is not None:
         stats = row_stats if (md == 2 and have_stats) else None     # (mode 2 without valid partials: the same tile takes its own statistics)
         fused_ = lambda t: fused(t, stats)  # noqa: E731
-        if LAUNCH_LOG is not None and a.is_cuda:
+        # The table key does not hold rows_per_batch: (2816, 3840, 1280, q|k|v^T) is level 2 at UNet batch 8 (352 tokens per image: fine) and
+        # level 3 at batch 32 (88 tokens: the folded instances need a multiple of 32 for the V^T pass and refuse).  A refusal (-1) comes
+        # before anything is launched: take the two-launch form then -- also inside a graph capture.
+        log = LAUNCH_LOG is not None and a.is_cuda
+        if log:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _chk(fused_(choice), "pcdm_gemm (LayerNorm folded)")
+        rc = fused_(choice)
+        if rc == -1 and not tile:
+            two_launches()
+            return out
+        _chk(rc, "pcdm_gemm (LayerNorm folded)")
+        if log:
             e1.record()
             LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, False, choice, 1), 2.0 * M * pw.alg_nk))
-        else:
-            _chk(fused_(choice), "pcdm_gemm (LayerNorm folded)")
         return out
     two_launches()
     return out
@@ -621,7 +628,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
     return out
 
 
-XATTN_QPROJ = os.environ.get("PCDM_XATTN_QPROJ", "1") != "0"   # A/B switch: the cross-attention's query projection inside the attention kernel
+XATTN_QPROJ = os.environ.get("PCDM_XATTN_QPROJ", "0") == "1"   # opt-in (measured slower than the two launches it replaces: profiles/r5_bench_xattn.txt)
 
 
 def flash_attn_qproj(x: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,

@@ -493,7 +493,10 @@ def test_flash_attn_qproj(backend, case):
     C = H * 64
     g = torch.Generator().manual_seed(470)
     x = torch.randn(B * Lq, C, generator=g) * (torch.rand(B * Lq, 1, generator=g) * 2 + 0.3)
-    x[::5] += 10.0                                                     # rows whose |mean| >> std
+    if case == "plain":
+        x = x * 0.4        # (no LayerNorm in front: keep the scores in the range LayerNorm'ed rows give -- a near-one-hot softmax turns a
+    else:                  #  bf16 flip of q into an O(1) output change, which is not what this test is about)
+        x[::5] += 10.0     # rows whose |mean| >> std
     x = x.to(BF16)
     wq = rnd(C, C, seed=471, scale=1 / math.sqrt(C))
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
