@@ -65,6 +65,12 @@ typedef struct pcdm_gn_splitk_src {
 int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* src, const void* x2, int C2, int B, int HW, int groups, float eps,
                           const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
 
+/* GroupNorm(+SiLU) of a tensor whose producer left its group sums (pcdm_gemm_params.gn_stats_out, part_rows = 192 rows per tile): merges the
+ * partials of each image (Chan) and normalises in one streaming pass -- no statistics pass, no exchange between workgroups.  x, y [B*HW, C]
+ * bf16, C = 320 or 640, HW % 64 == 0.  Same result as pcdm_groupnorm up to the summation order of the statistics. */
+int pcdm_groupnorm_from_stats(const void* x, int C, int B, int HW, int groups, float eps, const float* gamma, const float* beta, int fuse_silu,
+                              void* y, const float* gn_stats, int part_rows, pcdm_stream_t s);
+
 /* ---- K8 LayerNorm  [BasicTransformerBlock.norm1/2/3, diffusers attention.py]  x,y [rows,C] bf16 */
 int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma, const float* beta,
                    pcdm_stream_t s);
@@ -149,8 +155,14 @@ typedef struct pcdm_gemm_params {
                                    rows stored, [M][N / 32][2] fp32, from the bf16-rounded output values (bias / rowvec / residual included).  The
                                    producer of the rows a LayerNorm reads next (Transformer2DModel.proj_in, attn1 / attn2 .to_out + residual).
                                    N % 32 == 0 */
+    float* gn_stats_out;        /* tile 21 + PCDM_EPI_STORE (3x3 convolution or linear; else -1): also write the GROUP sums of the rows stored, for the GroupNorm
+                                   that reads the tensor next: [ceil(M / 192)][2][N / gn_stats_gs][2] fp32 = per 192-row tile and per image it touches
+                                   (slot 0: the image of its first row, slot 1: the next one) {sum, sum of squares} of every group of gn_stats_gs
+                                   channels over the tile's rows of that image, from the bf16-rounded output values.  pcdm_groupnorm_from_stats merges
+                                   them and only normalises.  M % 32 == 0, rows_per_batch % 32 == 0, >= 192, 80 % gn_stats_gs == 0 */
+    int32_t gn_stats_gs;
 } pcdm_gemm_params;
-/* pcdm_version() == 3: the struct above ends with ln_row_stats, row_stats_out (2: ended with dup_rows; 1: with ln_eps).  Zero-initialise it (memset) and build against
+/* pcdm_version() == 3: the struct above ends with ln_row_stats, row_stats_out, gn_stats_out, gn_stats_gs (2: ended with dup_rows; 1: with ln_eps).  Zero-initialise it (memset) and build against
  * the header of the library in use: a host compiled against an older header passes a shorter struct.  A host MUST compare
  * pcdm_version() with the PCDM_ABI_VERSION it was compiled against before its first pcdm_gemm call (the library reads the trailing fields
  * unconditionally).  bias, rowvec, ldrv and rowvec_step_stride must keep 16-byte alignment (4 floats): the epilogues load them as

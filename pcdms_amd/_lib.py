@@ -42,7 +42,7 @@ class GemmParams(C.Structure):
         ("zero_rows", C.c_int32),
         ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
         ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64), ("dup_rows", C.c_int32),
-        ("ln_row_stats", C.c_void_p), ("row_stats_out", C.c_void_p),
+        ("ln_row_stats", C.c_void_p), ("row_stats_out", C.c_void_p), ("gn_stats_out", C.c_void_p), ("gn_stats_gs", C.c_int32),
     ]
 
 
@@ -72,6 +72,7 @@ _SIGS = {
     "pcdm_groupnorm": ([_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_groupnorm_splitk": ([C.POINTER(GnSplitKSrc), _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_layernorm": ([_P, _P, _I, _I, _F, _P, _P, _P], C.c_int),
+    "pcdm_groupnorm_from_stats": ([_P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _I, _P], C.c_int),
     "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),
     "pcdm_flash_attn": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_flash_attn_thr": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _P], C.c_int),

@@ -183,6 +183,18 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         return pcdm_gemm_detail::launch_gemm_ext(a.ln_row_stats ? 2 : 1, tile, a, st);
     }
     if (a.ln_row_stats) return -1;
+    a.gn_stats_out = p->gn_stats_out;
+    a.gn_stats_gs = p->gn_stats_gs;
+    if (a.gn_stats_out) {
+        // GroupNorm-statistics producer (gemm_ext.hip, EXT = 4): a STORE launch on the full-row tile whose lean epilogue also leaves the per-group
+        // sums of the rows it stores.  Whole 32-row passes inside one image, wave column ranges (80) that are whole groups
+        if (tile != 21 || a.split_k > 1 || p->act || a.dup_rows || a.zero_rows || p->epilogue != PCDM_EPI_STORE || (p->N & 7) || (p->ldo & 7) || p->Npad % 320 ||
+            p->M % 32 || p->rows_per_batch % 32 || p->M % p->rows_per_batch || p->rows_per_batch < 192 || a.gn_stats_gs < 8 || 80 % a.gn_stats_gs ||
+            p->N % a.gn_stats_gs || a.row_stats_out || (p->residual && ((p->ldr & 7) || (p->res_mod > 0 && p->res_mod < p->M))))
+            return -1;
+        a.cin = p->conv ? p->cin : 0;   // (launch_gemm_ext tells the convolution from the linear instance by it)
+        return pcdm_gemm_detail::launch_gemm_ext(4, tile, a, st);
+    }
     if (a.row_stats_out) {
         // row-statistics producer (gemm_ext.hip): a linear STORE launch whose lean epilogue also writes the {sum, M2} of every 32-column run of
         // the rows it stores

@@ -38,6 +38,8 @@ struct GemmArgs {
     const float* ln_wsum;    // rowgemm only: the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
     float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
     const float* ln_row_stats;   // folded LayerNorm, tiled instances (gemm_ext.hip): [M][K / 32][2] partial {sum, M2} of the A rows, written by their producer
+    float* gn_stats_out;         // GroupNorm-statistics producer instances (EXT = 4): [tiles_m][2][N / gn_stats_gs][2] {sum, sum of squares}
+    int gn_stats_gs;             // channels per group
     float* row_stats_out;        // row-statistics producer instances: [M][N / 32][2] partials of the stored rows
     int dup_rows;       // conv, lean epilogue: also write rows m + dup_rows (their own rowvec / residual rows): pcdm_gemm_params.dup_rows
     int defer_reduce;   // split_k > 1: no reduce launch (pcdm_groupnorm_splitk consumes the partial slabs)

@@ -801,6 +801,39 @@ __global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const u16* __r
     }
 }
 
+// GroupNorm(+SiLU) APPLY with known statistics, in the access pattern of layernorm_rows_kernel (LPR lanes per row x OPL octets per lane, OPL
+// independent 16-byte loads in flight per lane): y = silu(x sc[b, c] + sh[b, c]) with sc = rstd[b, g(c)] gamma[c], sh = beta[c] - mean sc.
+// Round 5's bound measurement for "GroupNorm statistics from the producing GEMM + a lean normalise-only pass" (VERDICT r4 next #2): how fast
+// can the pass that remains be?  (tools/bench_gn_apply.py; not on any product path.)
+template <int LPR, int OPL>
+__global__ __launch_bounds__(kThreads) void gn_apply_rows_kernel(const u16* __restrict__ x, u16* __restrict__ y, int rows, int HW, int gs,
+                                                               const float* __restrict__ stat /* [B][C / gs][2] {mean, rstd} */,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int fuse_silu) {
+    constexpr int RPW = 64 / LPR, C = 8 * LPR * OPL;
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int row = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    if (row >= rows) return;
+    const int64_t base = (int64_t)row * C;
+    u16x8 u[OPL];
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) u[j] = *(const u16x8*)(x + base + (j * LPR + sub) * 8);
+    const float* st = stat + (int64_t)(row / HW) * (C / gs) * 2;
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int c = (j * LPR + sub) * 8;
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / gs;
+            const float sc = st[2 * g + 1] * gamma[c + e];
+            float f = (bf2f(u[j][e]) - st[2 * g]) * sc + beta[c + e];
+            if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
+            o[e] = f2bf(f);
+        }
+        *(u16x8*)(y + base + c) = o;
+    }
+}
+
 template <int LPR, int OPL>
 void launch_layernorm_rows(hipStream_t st, const u16* x, u16* y, int rows, float eps, const float* gamma, const float* beta) {
     constexpr int rpb = (kThreads / 64) * (64 / LPR);
@@ -1004,6 +1037,127 @@ extern "C" int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* p, const void* x2
     src.rowvec_step = p->rowvec ? p->rowvec_step : nullptr; src.rowvec_step_stride = p->rowvec_step_stride; src.residual = (const u16*)p->residual; src.ldr = (int)p->ldr;
     src.pre_out = p->store_pre ? (u16*)p->pre_out : nullptr;   // (the two-kernel path writes the buffer whatever the flag)
     return gn_launch(src, B, HW, groups, eps, gamma, beta, fuse_silu, y, ws, (hipStream_t)s, (u16*)p->pre_out);
+}
+
+// GroupNorm(+SiLU) of a tensor whose GROUP SUMS its producer already wrote (pcdm_gemm_params.gn_stats_out: per 192-row tile and image slot
+// {sum, sum of squares} of every group): the workgroup first merges the partials of ITS image -- thread (group, sub) Chan-merges every 8th
+// tile's {n, mean, M2 = q - s^2 / n}, the 8 subs are merged through LDS in a fixed order (deterministic) -- while its rows' loads are in
+// flight, then normalises in the access pattern of layernorm_rows_kernel.  One streaming pass: the statistics half of the GroupNorm
+// launch (read all -> exchange -> write all) is gone.
+template <int LPR, int OPL, int ITERS>
+__global__ __launch_bounds__(kThreads) void gn_from_stats_kernel(const u16* __restrict__ x, u16* __restrict__ y, int rows, int HW, int gs,
+                                                               const float* __restrict__ gp /* [tiles][2][G][2] */, int part_rows, float eps,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int fuse_silu) {
+    constexpr int RPW = 64 / LPR, C = 8 * LPR * OPL, RPB = (kThreads / 64) * RPW * ITERS;   // rows per workgroup (HW % RPB == 0: one image)
+    __shared__ float red[kThreads * 3];
+    __shared__ float stat[2 * 256];
+    const int t = threadIdx.x, lane = t & 63, sub = lane % LPR;
+    const int row0 = blockIdx.x * RPB;
+    const int G = C / gs;
+    u16x8 u[ITERS][OPL];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = row0 + (it * (kThreads / 64) + (t >> 6)) * RPW + lane / LPR;
+        const int64_t base = (int64_t)(row < rows ? row : rows - 1) * C;
+#pragma unroll
+        for (int j = 0; j < OPL; ++j) u[it][j] = *(const u16x8*)(x + base + (j * LPR + sub) * 8);
+    }
+    {   // ---- this image's statistics from the producer's partials
+        const int b = row0 / HW;
+        const int64_t i0 = (int64_t)b * HW, i1 = i0 + HW;          // rows of the image
+        const int t_lo = (int)(i0 / part_rows), t_hi = (int)((i1 - 1) / part_rows);
+        const int nsub = kThreads / G > 0 ? kThreads / G : 1;
+        const int sb = t / G, g = t - sb * G;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        if (sb < nsub) {
+            for (int tt = t_lo + sb; tt <= t_hi; tt += nsub) {
+                const int64_t r_lo = (int64_t)tt * part_rows, r_hi = r_lo + part_rows;
+                const int64_t o_lo = r_lo > i0 ? r_lo : i0, o_hi = r_hi < i1 ? r_hi : i1;
+                const float nj = (float)(o_hi - o_lo) * (float)gs;
+                const int slot = b - (int)(r_lo / HW);
+                const f32x2 sq = *(const f32x2*)(gp + (((int64_t)tt * 2 + slot) * G + g) * 2);
+                const float mj = sq[0] / nj;
+                gn_chan_merge(n, mean, m2, nj, mj, sq[1] - sq[0] * mj);
+            }
+        }
+        red[3 * t] = n;
+        red[3 * t + 1] = mean;
+        red[3 * t + 2] = m2;
+        __syncthreads();
+        if (t < G) {
+            n = mean = m2 = 0.f;
+            for (int j = 0; j < nsub; ++j) gn_chan_merge(n, mean, m2, red[3 * (j * G + t)], red[3 * (j * G + t) + 1], red[3 * (j * G + t) + 2]);
+            float var = n > 0.f ? m2 / n : 0.f;
+            var = var > 0.f ? var : 0.f;
+            stat[2 * t] = mean;
+            stat[2 * t + 1] = 1.0f / sqrtf(var + eps);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int c = (j * LPR + sub) * 8;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / gs;
+            sc[e] = stat[2 * g + 1] * gamma[c + e];
+            sh[e] = beta[c + e] - stat[2 * g] * sc[e];
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = row0 + (it * (kThreads / 64) + (t >> 6)) * RPW + lane / LPR;
+            if (row >= rows) continue;
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(u[it][j][e]) * sc[e] + sh[e];
+                if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
+                o[e] = f2bf(f);
+            }
+            *(u16x8*)(y + (int64_t)row * C + c) = o;
+        }
+    }
+}
+
+extern "C" int pcdm_groupnorm_from_stats(const void* x, int C, int B, int HW, int groups, float eps, const float* gamma, const float* beta, int fuse_silu,
+                                         void* y, const float* gn_stats, int part_rows, pcdm_stream_t s) {
+    if (!x || !y || !gn_stats || !gamma || !beta || B <= 0 || HW <= 0 || groups <= 0 || groups > 256 || (C != 320 && C != 640) || C % groups ||
+        part_rows <= 0 || part_rows > HW)
+        return -1;
+    const int rows = B * HW;
+    hipStream_t st = (hipStream_t)s;
+#define PCDM_GNFS(LPR_, IT_)                                                                                                              \
+    do {                                                                                                                                  \
+        constexpr int rpb = (kThreads / 64) * (64 / LPR_) * IT_;                                                                          \
+        if (HW % rpb) return -1;                                                                                                          \
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_from_stats_kernel<LPR_, 5, IT_>), dim3(rows / rpb), dim3(kThreads), 0, st, (const u16*)x, (u16*)y, rows, HW,     \
+                    C / groups, gn_stats, part_rows, eps, gamma, beta, fuse_silu);                                                        \
+    } while (0)
+    if (C == 320) PCDM_GNFS(8, 2);     // 64 rows per workgroup (704 workgroups at 8 x 5632 rows)
+    else PCDM_GNFS(16, 4);             // 64 rows per workgroup
+#undef PCDM_GNFS
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+// (measurement helper, see gn_apply_rows_kernel: C = 320 / 640 only)
+extern "C" int pcdm_dev_groupnorm_apply_rows(const void* x, void* y, int B, int HW, int C, int groups, const float* stat, const float* gamma,
+                                             const float* beta, int fuse_silu, pcdm_stream_t s) {
+    if (!x || !y || !stat || !gamma || !beta || B <= 0 || HW <= 0 || (C != 320 && C != 640) || groups <= 0 || C % groups) return -1;
+    const int rows = B * HW;
+    hipStream_t st = (hipStream_t)s;
+    if (C == 320) {
+        constexpr int rpb = (kThreads / 64) * (64 / 8);
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_apply_rows_kernel<8, 5>), dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, (const u16*)x, (u16*)y, rows, HW,
+                    C / groups, stat, gamma, beta, fuse_silu);
+    } else {
+        constexpr int rpb = (kThreads / 64) * (64 / 16);
+        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_apply_rows_kernel<16, 5>), dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, (const u16*)x, (u16*)y, rows, HW,
+                    C / groups, stat, gamma, beta, fuse_silu);
+    }
+    PCDM_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma,

@@ -186,10 +186,14 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride
         int64_t rowvec_step_stride = 0;
         int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
+        float* gn_stats = nullptr;    // producer: also write the GroupNorm partials of the stored rows (pcdm_gemm_params.gn_stats_out) when the
+        int gn_gs = 0;                //           configuration in use can (full-row tile, no split-K, ...); gn_gs = channels per group
         float* row_stats = nullptr;   // producer: write the LayerNorm partials of the stored rows here when the tile in use can (pcdm_gemm_params.row_stats_out);
                                       // consumer (gemm_ln): the partials of the A rows (used when stats_valid and the table asks for mode 2)
     };
     bool stats_valid = false;   // did the last gemm() that was handed G::row_stats write them?
+    const void* gn_stats_of = nullptr;   // the tensor the GroupNorm partials in "gns" describe (NULL: none), and their group size
+    int gn_stats_gs = 0;
     // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
     pcdm_gn_splitk_src pend;
     const void* pend_out = nullptr;
@@ -237,6 +241,14 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
                 p.ws_floats = kSplitKFloats;
                 if ((int64_t)p.split_k * M * w->Npad > kSplitKFloats) { p.split_k = 0; p.tile = 0; p.ws = nullptr; p.ws_floats = 0; }
             }
+        }
+        if (g.gn_stats) {    // (pcdms_amd.ops.gemm(gn_stats=): the same condition)
+            const int rpb = p.rows_per_batch;
+            const bool ok = !getenv_off("PCDM_GN_PRODUCER_STATS") && p.tile == 21 && p.split_k <= 1 && g.epilogue == PCDM_EPI_STORE && !g.dup_rows && !g.zero_rows &&
+                            !g.row_stats && g.gn_gs >= 8 && 80 % g.gn_gs == 0 && w->N % g.gn_gs == 0 && w->Npad % 320 == 0 && M % 32 == 0 && rpb % 32 == 0 &&
+                            M % rpb == 0 && rpb >= 192 && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0);
+            gn_stats_of = nullptr;
+            if (ok) { p.gn_stats_out = g.gn_stats; p.gn_stats_gs = g.gn_gs; gn_stats_of = out; gn_stats_gs = g.gn_gs; }
         }
         if (g.row_stats) {   // (pcdms_amd.ops.gemm(row_stats=): the same condition, so that both schedules launch the same instances)
             const int tl = p.tile;
@@ -293,8 +305,14 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         chk(pcdm_layernorm(a, ln_buf, M, w->K, eps, gamma, beta, st), "pcdm_layernorm");
         gemm(ln_buf, w->K, M, w, out, g);
     }
-    void groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, float eps, const float* gamma, const float* beta, int silu, void* y) {
+    void groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, float eps, const float* gamma, const float* beta, int silu, void* y,
+                   const float* gn_stats = nullptr) {
         if (rc) return;
+        const int G_ = u->cfg.norm_groups;
+        if (gn_stats && !pend_out && !x2 && gn_stats_of == x1 && (C1 == 320 || C1 == 640) && HW % 64 == 0 && C1 % G_ == 0 && gn_stats_gs == C1 / G_) {
+            chk(pcdm_groupnorm_from_stats(x1, C1, B, HW, G_, eps, gamma, beta, silu, y, gn_stats, 192, st), "pcdm_groupnorm_from_stats");
+            return;   // (the producer left the group sums: normalise only -- pcdms_amd.ops.groupnorm(gn_stats=))
+        }
         if (pend_out) {
             if (pend_out != x1 || pend.N != C1) { rc = -1; u->err = "deferred split-K reduce: the next GroupNorm reads another tensor"; return; }
             pend_out = nullptr;
@@ -385,6 +403,7 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
         }
     }
     for (const char* nm : {"r", "rb", "u", "ub", "r2", "c1", "sc", "t0", "t1", "ln", "q2", "at", "us"}) P.add(nm, act);
+    P.add("gns", ((int64_t)B * h * w / 192 + 2) * 2 * 256 * 2 * 4);   // GroupNorm partials: [tiles of 192 rows][2][groups <= 256][2] fp32
     P.add("rs", act / 8 + kAlign);   // LayerNorm partials: [M][C / 32][2] fp32 = an eighth of an activation's bytes
     P.add("gn", act_gn);
     P.add("ff", act_ff);
@@ -681,6 +700,8 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = hh; g.Wo = ww;
         g.rowvec = temb + toff.at(p); g.ldrv = temb_n; g.rows_per_batch = HW_;
         g.rowvec_step = rv_step; g.rowvec_step_stride = rv_stride;
+        float* gns = R.buf<float>("gns");   // GroupNorm partials of the tensor in flight (round 5; pcdms_amd/unet.py::resnet)
+        g.gn_stats = gns; g.gn_gs = cout / G;
         if (shared_in) {   // the CFG halves still have the same x1: norm1 and conv1's contraction once, two epilogues
             const int Bs = B / 2, Ms = Bs * HW_;
             chk_gn_half(x1, C1, Bs, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"));
@@ -691,7 +712,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             g.defer = 2;
             R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
         }
-        R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
+        R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"), gns);
         const void* res = x1;
         if (u->w.count(p + "conv_shortcut")) {
             Run::G gs;
@@ -702,6 +723,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         Run::G g2;
         g2.conv = 1; g2.B = B; g2.Hi = hh; g2.Wi = ww; g2.Ho = hh; g2.Wo = ww;
         g2.residual = res; g2.ldr = cout; g2.res_mod = M;
+        g2.rows_per_batch = HW_; g2.gn_stats = gns; g2.gn_gs = cout / G;
         g2.defer = gn_next ? 1 : 0;
         void* out = R.buf(out_name);
         R.gemm(R.buf("gn"), cout, M, cv2, out, g2);
@@ -711,7 +733,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     auto transformer = [&](const std::string& p, const void* x, int cc, int H, int HW_, const std::string& out_name) -> void* {
         const int M = B * HW_;
         const std::string b = p + "transformer_blocks.0.";
-        R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"));
+        R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"), R.buf<float>("gns"));
         const int64_t r0 = (int64_t)n0 * HW_;
         float* rs = R.buf<float>("rs");            // LayerNorm partials of the rows in flight: [M][cc / 32][2] (round 5; pcdms_amd/unet.py::transformer)
         auto twin = [&](const char* nm) -> const PW* { return u->w.count(p + nm) ? &u->w[p + nm] : nullptr; };

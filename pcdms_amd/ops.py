@@ -90,9 +90,21 @@ def as_tensor(x: Union[torch.Tensor, "DeferredGemm"]) -> torch.Tensor:
     return x.tensor() if isinstance(x, DeferredGemm) else x
 
 
+GN_PRODUCER_STATS = os.environ.get("PCDM_GN_PRODUCER_STATS", "1") != "0"   # A/B switch (round 5): GroupNorm statistics written by the producing GEMM
+GN_PART_ROWS = 192                                                          # rows per partial = BM of the producer tile (21)
+_GN_STATS_OF: dict = {}                                                     # stats storage -> (data_ptr of the tensor they describe, group size)
+
+
+def gn_stats_for(gn_stats: Optional[torch.Tensor], x: torch.Tensor, gs: int) -> bool:
+    """do the partials in ``gn_stats`` describe exactly the tensor ``x`` at group size ``gs`` (written by the ``gemm(..., gn_stats=)`` that produced it)?"""
+    return gn_stats is not None and torch.is_tensor(x) and _GN_STATS_OF.get(gn_stats.untyped_storage().data_ptr()) == (x.data_ptr(), gs)
+
+
 def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
-              gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
-    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16.  x1 may be a ``DeferredGemm``."""
+              gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor,
+              gn_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16.  x1 may be a ``DeferredGemm``.  ``gn_stats``: the group sums
+    the producer of x1 left (``gemm(..., gn_stats=)``); when they describe x1 the launch only normalises (pcdm_groupnorm_from_stats)."""
     C1 = x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
     _c(out, BF16); _c(gamma, torch.float32); _c(beta, torch.float32)
@@ -101,7 +113,11 @@ def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor
     if log:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if isinstance(x1, DeferredGemm):
+    if x2 is None and C1 in (320, 640) and HW % 64 == 0 and C1 % groups == 0 and gn_stats_for(gn_stats, x1, C1 // groups):
+        _c(x1, BF16)
+        _chk(_lib.lib().pcdm_groupnorm_from_stats(_ptr(x1), C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta), int(silu), _ptr(out), _ptr(gn_stats),
+                                                 GN_PART_ROWS, _stream(x1)), "pcdm_groupnorm_from_stats")
+    elif isinstance(x1, DeferredGemm):
         d = x1
         assert d.M == B * HW and d.N == C1 and (d.rowvec is None or d.rpb == HW), "rowvec rows must be the GroupNorm's batch entries"
         sp = _lib.GnSplitKSrc()
@@ -235,7 +251,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
          defer_reduce: Optional[bool] = None, dup_rows: int = 0, rowvec_step: Optional[torch.Tensor] = None,
-         rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None) -> Union[torch.Tensor, "DeferredGemm"]:
+         rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None, gn_stats: Optional[torch.Tensor] = None,
+         gn_gs: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
@@ -319,6 +336,19 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     elif split_k > 1:
         split = split_k
     p.tile = tile
+    if gn_stats is not None:
+        # producer of GroupNorm partials (pcdm_gemm_params.gn_stats_out: [ceil(M / 192)][2][N / gn_gs][2] fp32): the full-row tile's STORE epilogue
+        # only; any other configuration leaves the buffer alone and the GroupNorm that follows takes its own statistics
+        rpb_ = rows_per_batch or M
+        ok = GN_PRODUCER_STATS and tile == 21 and split == 1 and epilogue == EPI_STORE and act == ACT_NONE and not dup_rows and not zero_rows and \
+            row_stats is None and gn_gs >= 8 and 80 % gn_gs == 0 and pw.N % gn_gs == 0 and pw.Npad % 320 == 0 and M % 32 == 0 and rpb_ % 32 == 0 and \
+            M % rpb_ == 0 and rpb_ >= 192 and out.dim() == 2 and out.is_contiguous() and (residual is None or res_mod in (0, M))
+        if ok:
+            assert gn_stats.dtype == torch.float32 and gn_stats.is_contiguous() and gn_stats.numel() >= ((M + 191) // 192) * 2 * (pw.N // gn_gs) * 2
+            p.gn_stats_out, p.gn_stats_gs = _ptr(gn_stats), gn_gs
+            _GN_STATS_OF[gn_stats.untyped_storage().data_ptr()] = (out.data_ptr(), gn_gs)
+        else:
+            _GN_STATS_OF.pop(gn_stats.untyped_storage().data_ptr(), None)
     if row_stats is not None:
         # producer of LayerNorm partials (pcdm_gemm_params.row_stats_out): [M][N / 32][2] fp32, written by the STORE epilogue of the tiles that
         # have such an instance; any other configuration leaves the buffer alone and says so (the consumer then takes its own statistics)

@@ -624,6 +624,9 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             cin, cout, M = r["cin"], r["cout"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             tv = temb[:, r["toff"]: r["toff"] + cout]
+            # round 5: the convolutions also leave the GROUP sums of the rows they store (ops.gemm(gn_stats=): the full-row tile of level 0), so that
+            # the GroupNorm reading the tensor next -- norm2 after conv1, Transformer2DModel.norm after conv2 -- only normalises
+            gns = self._buf("gns", ((M + 191) // 192, 2, G, 2), torch.float32)
             if shared:   # the CFG halves still have the same x1 here: norm1 and conv1's contraction once, two epilogues (temb rows b / b + B/2)
                 Bs, Ms = B // 2, (B // 2) * HW_
                 n1 = ops.groupnorm(x1[:Ms], None, Bs, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin))[:Ms], ws)
@@ -635,20 +638,21 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
                 cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
                 h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False,
-                              rowvec_step=rv_step, rowvec_step_stride=rv_stride)
-            n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
+                              rowvec_step=rv_step, rowvec_step_stride=rv_stride, gn_stats=gns, gn_gs=cout // G)
+            n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws, gn_stats=gns)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
             else:
                 res = x1
             return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M,
-                            defer_reduce=True if gn_next else None)
+                            defer_reduce=True if gn_next else None, rows_per_batch=HW_, gn_stats=gns, gn_gs=cout // G)
 
         def transformer(p, x, HW_, name):
             a = W[p]
             c, H, M = a["c"], a["heads"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
-            n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
+            n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws,
+                               gn_stats=self._buf("gns", ((M + 191) // 192, 2, G, 2), torch.float32))
             x = ops.as_tensor(x)
             # Row statistics travel with the rows (round 5, levels 1-3): the linear that writes the input of a LayerNorm -- proj_in, attn1.to_out +
             # residual, attn2.to_out + residual -- also writes the {sum, M2} of every 32-column run (`row_stats`), and the LayerNorm-folded

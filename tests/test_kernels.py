@@ -980,6 +980,77 @@ def test_gemm_row_stats_producer_and_consumer(backend):
     assert not ops.row_stats_valid(st2)
 
 
+@pytest.mark.parametrize("kind", ["conv_rowvec", "conv_residual", "linear_residual"])
+def test_groupnorm_producer_statistics(backend, kind):
+    """Round 5: the GEMM that writes a tensor also leaves its GroupNorm group sums (``gemm(..., gn_stats=)``: tile 21, per 192-row tile and
+    image slot), and ``groupnorm(..., gn_stats=)`` then only normalises (pcdm_groupnorm_from_stats).  192-row tiles that straddle two
+    images, time-embedding rows / residuals in the producing epilogue, channel offsets of 20 standard deviations: the partials against
+    sums taken from the stored tensor, the normalised output against ``F.group_norm`` (fp64) and against the library's own
+    single-launch GroupNorm on the same tensor."""
+    dev = backend.device
+    g = torch.Generator().manual_seed(490)
+    B, H, W, C, G = (2, 8, 32, 320, 32) if backend.is_emu else (8, 64, 88, 320, 32)
+    HW, M, gs = H * W, B * H * W, C // G
+    cin = 64 if backend.is_emu else 320
+    gamma, beta = (torch.rand(C, generator=g) + 0.5), torch.randn(C, generator=g) * 0.5
+    stats = torch.full(((M + 191) // 192, 2, G, 2), float("nan"), dtype=torch.float32, device=dev)
+    out = torch.full((M, C), float("nan"), dtype=BF16, device=dev)
+    chan_off = (torch.randn(C, generator=g) * 20.0)                         # per-channel offsets >> the spread (bias of the producer)
+    if kind.startswith("conv"):
+        x = rnd(B, H, W, cin, seed=491)
+        w = rnd(C, cin, 3, 3, seed=492, scale=1 / math.sqrt(9 * cin))
+        pw = ops.pack_conv3x3(w.float(), chan_off, dev)
+        kw = dict(conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), rows_per_batch=HW)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), chan_off, padding=1).permute(0, 2, 3, 1).reshape(M, C)
+        if kind == "conv_rowvec":
+            tv = torch.randn(B, C, generator=g)
+            kw["rowvec"] = tv.to(dev)
+            ref = ref + tv.repeat_interleave(HW, 0)
+        else:
+            res = rnd(M, C, seed=493)
+            kw.update(residual=res.to(dev), res_mod=M)
+            ref = ref + res.float()
+        a = x.to(dev)
+    else:
+        a0 = rnd(M, cin, seed=494)
+        w = rnd(C, cin, seed=495, scale=1 / math.sqrt(cin))
+        pw = ops.pack_linear(w.float(), chan_off, dev)
+        res = rnd(M, C, seed=496)
+        kw = dict(residual=res.to(dev), res_mod=M, rows_per_batch=HW)
+        ref = a0.float() @ w.float().t() + chan_off + res.float()
+        a = a0.to(dev)
+    ops.gemm(a, pw, out, tile=21, gn_stats=stats, gn_gs=gs, **kw)
+    backend.sync()
+    assert ops.gn_stats_for(stats, out, gs)
+    close(out, ref)
+    # the partials against the stored tensor
+    o = out.float().cpu().view(M, G, gs)
+    got = stats.cpu()
+    for t in range((M + 191) // 192):
+        r0, r1 = t * 192, min(M, (t + 1) * 192)
+        b0 = r0 // HW
+        for slot in (0, 1):
+            lo, hi = max(r0, (b0 + slot) * HW), min(r1, (b0 + slot + 1) * HW)
+            if lo >= hi:
+                continue
+            blk = o[lo:hi]
+            want_s, want_q = blk.sum((0, 2)), (blk * blk).sum((0, 2))
+            assert (got[t, slot, :, 0] - want_s).abs().max() <= 1e-3 * want_s.abs().max() + 1e-2, (t, slot)
+            assert (got[t, slot, :, 1] - want_q).abs().max() <= 1e-3 * want_q.abs().max() + 1e-2, (t, slot)
+    # the normalise-only GroupNorm against the fp64 reference and the library's own single launch
+    ref_n = F.silu(F.group_norm(out.double().cpu().view(B, HW, C).permute(0, 2, 1), G, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1).reshape(M, C)
+    ws = ops.groupnorm_ws(B, C, dev)
+    y1, y2 = torch.full((M, C), float("nan"), dtype=BF16, device=dev), torch.empty(M, C, dtype=BF16, device=dev)
+    ops.groupnorm(out, None, B, HW, G, 1e-5, gamma.to(dev), beta.to(dev), True, y1, ws, gn_stats=stats)
+    ops.groupnorm(out, None, B, HW, G, 1e-5, gamma.to(dev), beta.to(dev), True, y2, ws)
+    backend.sync()
+    close(y1, ref_n, tol=6e-3)
+    close(y1, y2.float(), tol=6e-3)
+    # partials that describe ANOTHER tensor are not used
+    other = out.clone()
+    assert not ops.gn_stats_for(stats, other, gs)
+
+
 def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:
     bits = torch.arange(0, 1 << 16, dtype=torch.int32)
     v = bits.to(torch.int16).view(BF16)
