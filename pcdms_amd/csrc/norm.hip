@@ -1097,12 +1097,16 @@ __global__ __launch_bounds__(kThreads) void gn_from_stats_kernel(const u16* __re
 #pragma unroll
     for (int j = 0; j < OPL; ++j) {
         const int c = (j * LPR + sub) * 8;
+        // an octet spans at most two groups (gs >= 8): one division per octet, 16-byte loads of the affine
+        const int g0 = c / gs, brk = (g0 + 1) * gs - c;          // channels e >= brk belong to group g0 + 1
+        const f32x2 s0 = *(const f32x2*)(stat + 2 * g0), s1 = *(const f32x2*)(stat + 2 * (g0 + 1 < G ? g0 + 1 : g0));
+        const f32x4 ga = *(const f32x4*)(gamma + c), gb = *(const f32x4*)(gamma + c + 4), ba = *(const f32x4*)(beta + c), bb = *(const f32x4*)(beta + c + 4);
         float sc[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / gs;
-            sc[e] = stat[2 * g + 1] * gamma[c + e];
-            sh[e] = beta[c + e] - stat[2 * g] * sc[e];
+            const float mean_e = e < brk ? s0[0] : s1[0], rstd_e = e < brk ? s0[1] : s1[1];
+            sc[e] = rstd_e * (e < 4 ? ga[e & 3] : gb[e & 3]);
+            sh[e] = (e < 4 ? ba[e & 3] : bb[e & 3]) - mean_e * sc[e];
         }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
