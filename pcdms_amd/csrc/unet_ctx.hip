@@ -244,7 +244,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         }
         if (g.gn_stats) {    // (pcdms_amd.ops.gemm(gn_stats=): the same condition)
             const int rpb = p.rows_per_batch;
-            const bool ok = !getenv_off("PCDM_GN_PRODUCER_STATS") && p.tile == 21 && p.split_k <= 1 && g.epilogue == PCDM_EPI_STORE && !g.dup_rows && !g.zero_rows &&
+            const char* gn_env = getenv("PCDM_GN_PRODUCER_STATS");   // (opt-in: measured break-even, profiles/r5_bench_gn_apply.txt)
+            const bool ok = gn_env && gn_env[0] == '1' && p.tile == 21 && p.split_k <= 1 && g.epilogue == PCDM_EPI_STORE && !g.dup_rows && !g.zero_rows &&
                             !g.row_stats && g.gn_gs >= 8 && 80 % g.gn_gs == 0 && w->N % g.gn_gs == 0 && w->Npad % 320 == 0 && M % 32 == 0 && rpb % 32 == 0 &&
                             M % rpb == 0 && rpb >= 192 && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0);
             gn_stats_of = nullptr;

@@ -90,7 +90,8 @@ def as_tensor(x: Union[torch.Tensor, "DeferredGemm"]) -> torch.Tensor:
     return x.tensor() if isinstance(x, DeferredGemm) else x
 
 
-GN_PRODUCER_STATS = os.environ.get("PCDM_GN_PRODUCER_STATS", "1") != "0"   # A/B switch (round 5): GroupNorm statistics written by the producing GEMM
+GN_PRODUCER_STATS = os.environ.get("PCDM_GN_PRODUCER_STATS", "0") == "1"   # opt-in (round 5): GroupNorm statistics written by the producing GEMM -- measured
+#                                                                             break-even (profiles/r5_bench_gn_apply.txt: convolution +3..5 us, GroupNorm 22.0 -> 15.6 us, end to end +0.07 %)
 GN_PART_ROWS = 192                                                          # rows per partial = BM of the producer tile (21)
 _GN_STATS_OF: dict = {}                                                     # stats storage -> (data_ptr of the tensor they describe, group size)
 

@@ -988,6 +988,9 @@ def test_groupnorm_producer_statistics(backend, kind):
     sums taken from the stored tensor, the normalised output against ``F.group_norm`` (fp64) and against the library's own
     single-launch GroupNorm on the same tensor."""
     dev = backend.device
+    monkey = pytest.MonkeyPatch()
+    monkey.setattr(ops, "GN_PRODUCER_STATS", True)      # (opt-in in the product: PCDM_GN_PRODUCER_STATS=1)
+    request_finalizer = monkey.undo
     g = torch.Generator().manual_seed(490)
     B, H, W, C, G = (2, 8, 32, 320, 32) if backend.is_emu else (8, 64, 88, 320, 32)
     HW, M, gs = H * W, B * H * W, C // G
@@ -1049,6 +1052,7 @@ def test_groupnorm_producer_statistics(backend, kind):
     # partials that describe ANOTHER tensor are not used
     other = out.clone()
     assert not ops.gn_stats_for(stats, other, gs)
+    request_finalizer()
 
 
 def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:
