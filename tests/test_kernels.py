@@ -981,16 +981,14 @@ def test_gemm_row_stats_producer_and_consumer(backend):
 
 
 @pytest.mark.parametrize("kind", ["conv_rowvec", "conv_residual", "linear_residual"])
-def test_groupnorm_producer_statistics(backend, kind):
+def test_groupnorm_producer_statistics(backend, kind, monkeypatch):
     """Round 5: the GEMM that writes a tensor also leaves its GroupNorm group sums (``gemm(..., gn_stats=)``: tile 21, per 192-row tile and
     image slot), and ``groupnorm(..., gn_stats=)`` then only normalises (pcdm_groupnorm_from_stats).  192-row tiles that straddle two
     images, time-embedding rows / residuals in the producing epilogue, channel offsets of 20 standard deviations: the partials against
     sums taken from the stored tensor, the normalised output against ``F.group_norm`` (fp64) and against the library's own
     single-launch GroupNorm on the same tensor."""
     dev = backend.device
-    monkey = pytest.MonkeyPatch()
-    monkey.setattr(ops, "GN_PRODUCER_STATS", True)      # (opt-in in the product: PCDM_GN_PRODUCER_STATS=1)
-    request_finalizer = monkey.undo
+    monkeypatch.setattr(ops, "GN_PRODUCER_STATS", True)      # (opt-in in the product: PCDM_GN_PRODUCER_STATS=1; undone by the fixture, also on failure)
     g = torch.Generator().manual_seed(490)
     B, H, W, C, G = (2, 8, 32, 320, 32) if backend.is_emu else (8, 64, 88, 320, 32)
     HW, M, gs = H * W, B * H * W, C // G
@@ -1052,7 +1050,6 @@ def test_groupnorm_producer_statistics(backend, kind):
     # partials that describe ANOTHER tensor are not used
     other = out.clone()
     assert not ops.gn_stats_for(stats, other, gs)
-    request_finalizer()
 
 
 def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:
