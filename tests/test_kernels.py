@@ -1037,7 +1037,10 @@ def test_groupnorm_producer_statistics(backend, kind, monkeypatch):
             blk = o[lo:hi]
             want_s, want_q = blk.sum((0, 2)), (blk * blk).sum((0, 2))
             assert (got[t, slot, :, 0] - want_s).abs().max() <= 1e-3 * want_s.abs().max() + 1e-2, (t, slot)
-            assert (got[t, slot, :, 1] - want_q).abs().max() <= 1e-3 * want_q.abs().max() + 1e-2, (t, slot)
+            # (the partials are taken from the fp32 values in front of the bf16 rounding -- the 192 x 320 tile has no registers to spare for the
+            #  rounded copies --, the reference sums from the stored bf16 tensor: 2^-9 relative per element, a few 1e-3 on a sum of squares whose
+            #  terms share the sign of a large channel offset)
+            assert (got[t, slot, :, 1] - want_q).abs().max() <= 4e-3 * want_q.abs().max() + 1e-2, (t, slot)
     # the normalise-only GroupNorm against the fp64 reference and the library's own single launch
     ref_n = F.silu(F.group_norm(out.double().cpu().view(B, HW, C).permute(0, 2, 1), G, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1).reshape(M, C)
     ws = ops.groupnorm_ws(B, C, dev)
