@@ -36,3 +36,4 @@ rm -rf $OUT/step_a
 (timeout 300 python bench.py --no-cpu-baseline --no-vae --attn fp8 2>/dev/null) > $OUT/bench_attn_fp8.json
 (timeout 300 python bench.py --no-cpu-baseline --no-vae --batch 8 2>/dev/null) > $OUT/bench_batch8.json
 cut -c1-400 $OUT/bench.json; tail -12 $OUT/kernel_step_summary.txt; tail -4 $OUT/step_breakdown.txt; cat $OUT/three_stage.json | cut -c1-300
+(timeout 300 python -m pytest tests/test_kernels.py -m gpu -q -k "groupnorm_producer" 2>&1 | tail -3) > $OUT/rerun_producer_test.txt; cat $OUT/rerun_producer_test.txt
