@@ -116,11 +116,15 @@ __device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t so
 __device__ __forceinline__ u32x4 buf_load16(BufRsrc r, uint32_t voff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, 0));
 }
-// PCDM_STORE_AUX: cache-policy bits of the epilogues' output stores (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  A/B knob
-// (PCDM_BUILD_DEFINES="PCDM_STORE_AUX=2"): non-temporal output stores, so that an epilogue's write stream does not evict the weight /
-// activation tiles the other workgroups of the launch are still re-reading from the L2
+// PCDM_STORE_AUX: cache-policy bits of the kernels' OUTPUT stores (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Round 5: **16 (sc1, agent scope) is
+// the default**: an agent-scope store is written through the XCD's private L2 while the kernel runs, so the launch does not end with a burst
+// write-back of up to 32 MB of dirty lines in front of the next (dependent) launch -- which has to wait for exactly that write-back, since the
+// eight L2s are not coherent with each other.  Same-box A/B of the GEMM / rowgemm epilogue stores alone (profiles/r5_ab_store_scope.json):
+// sc1 +0.7 % / +0.4 % (two boxes), sc0 sc1 +0.7 %, sc0 -0.1 %, nt (round 2) -1.8 %.  NOT for the norms' / the attention's outputs and the split-K
+// slabs: with those written through as well the step was 1.2 % SLOWER (norm outputs alone -0.3 %: their consumer, a 3x3 convolution, reads its
+// input nine times and found the lines in the L2 before; attention outputs alone -1.1 %: 8-byte stores per lane).  PCDM_BUILD_DEFINES="PCDM_STORE_AUX=0": the write-back stores of rounds 1-4.
 #ifndef PCDM_STORE_AUX
-#define PCDM_STORE_AUX 0
+#define PCDM_STORE_AUX 16
 #endif
 __device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r.r, voff, 0, PCDM_STORE_AUX);
