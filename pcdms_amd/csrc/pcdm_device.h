@@ -103,6 +103,7 @@ __device__ __forceinline__ u32x4 buf_load16(BufRsrc r, uint32_t voff) {
 __device__ __forceinline__ void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
     if (voff < r.size && voff + 16 <= r.size) memcpy(const_cast<char*>(r.base) + voff, &v, 16);
 }
+__device__ __forceinline__ u32x4 buf_load16_once(BufRsrc r, uint32_t voff) { return buf_load16(r, voff); }
 #else
 struct BufRsrc { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, uint32_t bytes = 0x7fffffffu) {
@@ -115,6 +116,15 @@ __device__ __forceinline__ void buf_glds16(BufRsrc r, uint32_t voff, uint32_t so
 // drops the store -- rows beyond the tensor and masked lanes (voff bit 31) need no predicate and no branch
 __device__ __forceinline__ u32x4 buf_load16(BufRsrc r, uint32_t voff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, 0));
+}
+// residual rows of an epilogue: read exactly once per launch -> nt (streaming: they do not displace the operand tiles in the L2).  Same-box A/B
+// +0.15 % in both interleaved pairs (profiles/r5_ab_load_policy.json: at the edge of the 0.1 % repeatability; the same hint on the GroupNorm inputs
+// was 0.35 % slower and is not used).  PCDM_BUILD_DEFINES="PCDM_RESLOAD_AUX=0": plain loads.
+#ifndef PCDM_RESLOAD_AUX
+#define PCDM_RESLOAD_AUX 2
+#endif
+__device__ __forceinline__ u32x4 buf_load16_once(BufRsrc r, uint32_t voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, PCDM_RESLOAD_AUX));
 }
 // PCDM_STORE_AUX: cache-policy bits of the kernels' OUTPUT stores (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Round 5: **16 (sc1, agent scope) is
 // the default**: an agent-scope store is written through the XCD's private L2 while the kernel runs, so the launch does not end with a burst

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, WGM* WGN == 4 ? 2 : 1) void rowgemm_
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int m = m0 + j * 16 + it * RPI + rl;
-                rv[j][it] = buf_load16(rs_r, nok ? (uint32_t)(((int64_t)m * p.ldr + n) * 2) : kOOB);
+                rv[j][it] = buf_load16_once(rs_r, nok ? (uint32_t)(((int64_t)m * p.ldr + n) * 2) : kOOB);
             }
 #pragma unroll
         for (int j = 0; j < FMW; ++j) {
