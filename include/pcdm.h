@@ -127,7 +127,8 @@ typedef struct pcdm_gemm_params {
     int32_t zero_rows; /* linear only: the caller guarantees A rows [0, zero_rows) are all-zero; they are not read and tiles entirely
                           inside them run the epilogue only.  The CFG unconditional half of attn2.to_out: context == 0 => attention
                           output == 0 => out = bias + residual (stage2_inpaint_pipeline.py:457-458) */
-    const float* ln_wsum;  /* non-NULL (tiles 31..36 only: the A-in-registers kernel, K = 320): W and bias carry a FOLDED LayerNorm -- W' = W diag(gamma),
+    const float* ln_wsum;  /* non-NULL (tiles 31..36: the A-in-registers kernel, K = 320; tiles 2 / 4 / 7 / 8 / 17 / 18 / 26: the folded instances of the tiled
+                              kernel, any K, see ln_row_stats): W and bias carry a FOLDED LayerNorm -- W' = W diag(gamma),
                               bias' = bias + W beta (BasicTransformerBlock.norm1/2/3 in front of to_q|k|v, to_q and the GEGLU projection: K8 fused into
                               K7 / K11) -- and ln_wsum[n] = sum_k W'[n, k] (fp32 [Npad], of the bf16 values).  The kernel takes each A row's mean / rstd
                               (eps ln_eps) and returns rstd (acc - mean ln_wsum[n]) + bias'[n] = LayerNorm(A) W^T + bias.  Other tiles return -1 when set */

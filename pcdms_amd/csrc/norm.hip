@@ -801,39 +801,6 @@ __global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const u16* __r
     }
 }
 
-// GroupNorm(+SiLU) APPLY with known statistics, in the access pattern of layernorm_rows_kernel (LPR lanes per row x OPL octets per lane, OPL
-// independent 16-byte loads in flight per lane): y = silu(x sc[b, c] + sh[b, c]) with sc = rstd[b, g(c)] gamma[c], sh = beta[c] - mean sc.
-// Round 5's bound measurement for "GroupNorm statistics from the producing GEMM + a lean normalise-only pass" (VERDICT r4 next #2): how fast
-// can the pass that remains be?  (tools/bench_gn_apply.py; not on any product path.)
-template <int LPR, int OPL>
-__global__ __launch_bounds__(kThreads) void gn_apply_rows_kernel(const u16* __restrict__ x, u16* __restrict__ y, int rows, int HW, int gs,
-                                                               const float* __restrict__ stat /* [B][C / gs][2] {mean, rstd} */,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int fuse_silu) {
-    constexpr int RPW = 64 / LPR, C = 8 * LPR * OPL;
-    const int lane = threadIdx.x & 63, sub = lane % LPR;
-    const int row = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
-    if (row >= rows) return;
-    const int64_t base = (int64_t)row * C;
-    u16x8 u[OPL];
-#pragma unroll
-    for (int j = 0; j < OPL; ++j) u[j] = *(const u16x8*)(x + base + (j * LPR + sub) * 8);
-    const float* st = stat + (int64_t)(row / HW) * (C / gs) * 2;
-#pragma unroll
-    for (int j = 0; j < OPL; ++j) {
-        const int c = (j * LPR + sub) * 8;
-        u16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / gs;
-            const float sc = st[2 * g + 1] * gamma[c + e];
-            float f = (bf2f(u[j][e]) - st[2 * g]) * sc + beta[c + e];
-            if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
-            o[e] = f2bf(f);
-        }
-        *(u16x8*)(y + base + c) = o;
-    }
-}
-
 template <int LPR, int OPL>
 void launch_layernorm_rows(hipStream_t st, const u16* x, u16* y, int rows, float eps, const float* gamma, const float* beta) {
     constexpr int rpb = (kThreads / 64) * (64 / LPR);
@@ -1141,25 +1108,6 @@ extern "C" int pcdm_groupnorm_from_stats(const void* x, int C, int B, int HW, in
     if (C == 320) PCDM_GNFS(8, 2);     // 64 rows per workgroup (704 workgroups at 8 x 5632 rows)
     else PCDM_GNFS(16, 4);             // 64 rows per workgroup
 #undef PCDM_GNFS
-    PCDM_CHECK_LAUNCH();
-    return 0;
-}
-
-// (measurement helper, see gn_apply_rows_kernel: C = 320 / 640 only)
-extern "C" int pcdm_dev_groupnorm_apply_rows(const void* x, void* y, int B, int HW, int C, int groups, const float* stat, const float* gamma,
-                                             const float* beta, int fuse_silu, pcdm_stream_t s) {
-    if (!x || !y || !stat || !gamma || !beta || B <= 0 || HW <= 0 || (C != 320 && C != 640) || groups <= 0 || C % groups) return -1;
-    const int rows = B * HW;
-    hipStream_t st = (hipStream_t)s;
-    if (C == 320) {
-        constexpr int rpb = (kThreads / 64) * (64 / 8);
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_apply_rows_kernel<8, 5>), dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, (const u16*)x, (u16*)y, rows, HW,
-                    C / groups, stat, gamma, beta, fuse_silu);
-    } else {
-        constexpr int rpb = (kThreads / 64) * (64 / 16);
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_apply_rows_kernel<16, 5>), dim3((rows + rpb - 1) / rpb), dim3(kThreads), 0, st, (const u16*)x, (u16*)y, rows, HW,
-                    C / groups, stat, gamma, beta, fuse_silu);
-    }
     PCDM_CHECK_LAUNCH();
     return 0;
 }

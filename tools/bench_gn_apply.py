@@ -1,20 +1,18 @@
 #!/usr/bin/env python3
-"""Bound measurement for "GroupNorm statistics from the producer + a normalise-only pass" (bound-first rule): the one-pass
-GroupNorm(+SiLU) APPLY with known statistics, written in the access pattern of the LayerNorm rows kernel (pcdm_dev_groupnorm_apply_rows),
-against the product's single-launch GroupNorm (cluster kernel) and the LayerNorm rows kernel on the same tensors -- replayed hipGraphs of
-20 calls, UNet batch 8.
+"""Bound measurement for "GroupNorm statistics from the producer + a normalise-only pass" (bound-first rule): what a
+one-pass stream of the tensor costs (the LayerNorm rows kernel) against the product's single-launch GroupNorm (cluster kernel), then -- with
+PCDM_GN_PRODUCER_STATS=1 -- what the group sums cost the producing convolution and what the normalise-only launch takes; replayed hipGraphs
+of 20 calls, UNet batch 8.  (profiles/r5_bench_gn_apply.txt also has a line of a stand-alone apply kernel that was removed again.)
 
     python tools/bench_gn_apply.py > gpurun_out/bench_gn_apply.txt
 """
-import ctypes as C
 import sys
 from pathlib import Path
 
 import torch
-import torch.nn.functional as F
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from pcdms_amd import _lib, ops  # noqa: E402
+from pcdms_amd import ops  # noqa: E402
 from tools.bench_ln_gemm import timed  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -22,38 +20,24 @@ BF16 = torch.bfloat16
 
 
 def main():
-    lib = _lib.lib()
-    lib.pcdm_dev_groupnorm_apply_rows.restype = C.c_int
-    lib.pcdm_dev_groupnorm_apply_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    """the bound: the product's single-launch GroupNorm against the LayerNorm rows kernel (a one-pass stream of the same tensor)"""
     g = torch.Generator().manual_seed(0)
     for B, HW, Cc, n in [(8, 5632, 320, 12), (8, 1408, 640, 11), (8, 5632, 640, 2)]:
         x = (torch.randn(B * HW, Cc, generator=g) + 0.5).to(BF16).to(dev)
         gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.2).to(dev)
-        xr = x.float().view(B, HW, 32, Cc // 32)
-        mean = xr.mean((1, 3))
-        rstd = (xr.var((1, 3), unbiased=False) + 1e-5).rsqrt()
-        stat = torch.stack([mean, rstd], -1).contiguous()
-        y1, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        y2, y3 = torch.empty_like(x), torch.empty_like(x)
         ws = ops.groupnorm_ws(B, Cc, dev)
-
-        def apply_rows():   # (the stream is looked up per call: inside the graph capture it is the capturing stream)
-            assert lib.pcdm_dev_groupnorm_apply_rows(x.data_ptr(), y1.data_ptr(), B, HW, Cc, 32, stat.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
-                                                     torch.cuda.current_stream().cuda_stream) == 0
-        t_apply = timed(apply_rows)
         t_gn = timed(lambda: ops.groupnorm(x, None, B, HW, 32, 1e-5, gamma, beta, True, y2, ws))
         t_ln = timed(lambda: ops.layernorm(x, gamma, beta, 1e-5, y3))
-        torch.cuda.synchronize()
-        ref = F.silu(F.group_norm(x.float().view(B, HW, Cc).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(B * HW, Cc)
-        e1 = ((y1.float() - ref).norm() / ref.norm()).item()
-        e2 = ((y2.float() - ref).norm() / ref.norm()).item()
         mb = 2.0 * B * HW * Cc * 2 / 1e6
-        print(f"B {B} HW {HW} C {Cc} ({mb:.1f} MB read + written) x{n} per step: apply with known statistics {t_apply:6.2f} us ({mb / t_apply / 1e3 * 1e3:.0f} GB/s, rel {e1:.1e}) | "
-              f"GroupNorm launch (statistics + apply) {t_gn:6.2f} us (rel {e2:.1e}) | LayerNorm rows kernel {t_ln:6.2f} us", flush=True)
+        print(f"B {B} HW {HW} C {Cc} ({mb:.1f} MB read + written) x{n} per step: GroupNorm launch (statistics + apply) {t_gn:6.2f} us | "
+              f"LayerNorm rows kernel (one streaming pass) {t_ln:6.2f} us", flush=True)
 
 
 def producer():
     """what the group sums cost the convolution that writes them, and the normalise-only launch that uses them (level 0, UNet batch 8)"""
     import math
+    ops.GN_PRODUCER_STATS = True     # (opt-in in the product)
     g = torch.Generator().manual_seed(1)
     B, H, W, C = 8, 64, 88, 320
     M, HW = B * H * W, H * W
