@@ -224,6 +224,55 @@ def test_splitk_deferral_through_both_schedules(backend, monkeypatch):
     assert torch.equal(out_c, ref_py), (out_c - ref_py).abs().max()
 
 
+def test_layernorm_partials_through_both_schedules(backend, monkeypatch):
+    """Round 5 at the level of a whole forward: the LayerNorm -> Linear pairs of the tiny UNet forced onto the folded instances with producer
+    partials (table entries (tile, mode 2) for the ``ln`` keys, the linears that write the LayerNorm inputs on a tile that has a statistics
+    instance).  The Python schedule and ``pcdm_unet_forward`` must agree BIT FOR BIT -- including where the folded form is refused (16 tokens
+    per image: the V^T pass wants multiples of 32) and both fall back to LayerNorm + GEMM --, the result must stay within the forward
+    tolerance of the unforced schedule, and LayerNorm launches must actually disappear."""
+    cfg = UNetConfig.tiny()
+    B, h, w, L, n0 = (2, 8, 8, 5, 1) if backend.is_emu else (4, 16, 24, 9, 2)
+
+    class Rec(dict):
+        seen: list = []
+
+        def get(self, k, d=None):
+            self.seen.append(k)
+            return super().get(k, d)
+
+    rec = Rec(ops._TUNED)
+    monkeypatch.setattr(ops, "_TUNED", rec)
+    calls = []
+    orig_ln = ops.layernorm
+    monkeypatch.setattr(ops, "layernorm", lambda *a, **k: (calls.append(1), orig_ln(*a, **k))[1])
+    _, _, ref_py, ref_c = _run_both(backend, cfg, B, h, w, L, n0)      # records the keys (and tunes them on the GPU)
+    assert torch.equal(ref_py, ref_c)
+    n_plain = len(calls)
+    widths = set(cfg.block_out_channels)
+    forced_ln = forced_prod = 0
+    for k in set(rec.seen):
+        if k[0] == "ln":
+            _, M, Npad, K, epi = k
+            if K % 64 == 0 and K != 320:
+                tile = 4 if (epi == ops.EPI_GEGLU and Npad % 128 == 0) else 2
+                if epi != ops.EPI_GEGLU or Npad % 128 == 0:
+                    dict.__setitem__(rec, k, (tile, 2))
+                    forced_ln += 1
+        elif isinstance(k[0], int) and not k[3] and k[6] == ops.EPI_STORE and k[2] in widths and k[1] == k[2] and not k[7] and len(k) == 9:
+            dict.__setitem__(rec, k, (2, 1))      # proj_in / to_out (+ residual): 64 x 64 tiles, a row-statistics producer instance
+            forced_prod += 1
+        elif isinstance(k[0], int) and not k[3] and k[6] == ops.EPI_STORE and k[2] in widths and k[1] == k[2] and len(k) == 10 and k[9] is True:
+            dict.__setitem__(rec, k, (2, 1))      # attn2.to_out with the zero-context rows
+            forced_prod += 1
+    assert forced_ln >= 6 and forced_prod >= 4, (forced_ln, forced_prod)
+    del calls[:]
+    _, _, out_py, out_c = _run_both(backend, cfg, B, h, w, L, n0)
+    assert torch.equal(out_py, out_c), (out_py - out_c).abs().max()
+    assert len(calls) < n_plain, (len(calls), n_plain)
+    rel = ((out_py - ref_py).norm() / ref_py.norm()).item()
+    assert rel <= 1e-2, rel
+
+
 def test_cfg_shared_prefix_is_exact(backend, monkeypatch):
     """The CFG-shared prefix (``prepare_conditioning(shared_cfg_input=True)`` / ``pcdm_unet_set_shared_cfg_input``): with both halves of
     the batch carrying the same sample and pose, conv_in, the first norm1 and the first conv1's contraction run once for B/2 entries and
