@@ -245,9 +245,15 @@ def test_layernorm_partials_through_both_schedules(backend, monkeypatch):
     calls = []
     orig_ln = ops.layernorm
     monkeypatch.setattr(ops, "layernorm", lambda *a, **k: (calls.append(1), orig_ln(*a, **k))[1])
-    _, _, ref_py, ref_c = _run_both(backend, cfg, B, h, w, L, n0)      # records the keys (and tunes them on the GPU)
+    # reference: every LayerNorm as its own launch (on the GPU the online tuner would otherwise pick folded forms already); the lookups of
+    # this run are recorded -- the ``ln`` keys too
+    monkeypatch.setattr(ops, "LN_TILED", False)
+    monkeypatch.setenv("PCDM_LN_TILED", "0")
+    _, _, ref_py, ref_c = _run_both(backend, cfg, B, h, w, L, n0)
     assert torch.equal(ref_py, ref_c)
     n_plain = len(calls)
+    monkeypatch.setattr(ops, "LN_TILED", True)
+    monkeypatch.setenv("PCDM_LN_TILED", "1")
     widths = set(cfg.block_out_channels)
     forced_ln = forced_prod = 0
     for k in set(rec.seen):
