@@ -315,17 +315,31 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
     // sum over all keys: the MFMA contracts over both lane halves; the VALU partial sums are combined here
     const float l_tot = ROWSUM_VALU ? lacc[0] + __shfl_xor(lacc[0], 32, 64) : lacc[0];
     const float inv = 1.0f / l_tot;
-    if (qvalid) {
-        u16* op = o + ((int64_t)b * Lq + qrow) * ldo + h * 64;
+    // Output through LDS, whole rows (round 5; cdna_hip_programming.md T21): the accumulators hold 4 consecutive head dims of ONE query per
+    // register quad, so direct stores are 8-byte pieces of 32 different 128-byte lines per instruction, 8 instructions per lane -- a
+    // store-issue-bound tail.  The wave transposes its 32 x 64 tile through a private slice of the (now idle) K / V^T buffers (pitch 72
+    // elements) and writes 4 x 16 bytes per lane: every instruction covers 8 complete 128-byte rows.
+    __syncthreads();                                       // every wave is done reading the last K / V^T tile
+    constexpr int OP = 72;                                 // u16 pitch of a staged row (144 B: 16-byte aligned, rows 36 banks apart)
+    u16* ot = (u16*)&KV[0][0][0] + wave * (QPW * OP);
 #pragma unroll
-        for (int df = 0; df < 2; ++df)
+    for (int df = 0; df < 2; ++df)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                u16x4 ov;
+        for (int rg = 0; rg < 4; ++rg) {
+            u16x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = f2bf(oacc[df][4 * rg + e] * inv);
-                *(u16x4*)(op + df * 32 + 8 * rg + 4 * hh) = ov;
-            }
+            for (int e = 0; e < 4; ++e) ov[e] = f2bf(oacc[df][4 * rg + e] * inv);
+            *(u16x4*)(ot + col * OP + df * 32 + 8 * rg + 4 * hh) = ov;
+        }
+    PCDM_WAVE_SYNC();
+    {
+        const int rsub = lane >> 3, ch = lane & 7;
+        u16* ob = o + ((int64_t)b * Lq + q0) * ldo + h * 64 + ch * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 8 + rsub;
+            if (q0 + r < Lq) *(u16x8*)(ob + (int64_t)r * ldo) = *(const u16x8*)(ot + r * OP + ch * 8);
+        }
     }
 }
 // ---- N4: the same attention with e4m3 operands on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), twice the
@@ -541,7 +555,7 @@ static int g_lds_pad = [] { const char* e = getenv("PCDM_ATTN_LDS_PAD"); return 
 extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                    void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s) {
     if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
-    if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < Lk) return -1;
+    if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 8 || ldvt < Lk) return -1;
     if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
@@ -561,7 +575,7 @@ extern "C" int pcdm_flash_attn_qproj(const void* x, int64_t ldx, int C, const vo
                                      const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Lq, int Lk,
                                      float scale, pcdm_stream_t s) {
     if (!x || !wq || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || C <= 0) return -1;
-    if (C % 64 || ldx % 8 || ldx < C || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < Lk) return -1;
+    if (C % 64 || ldx % 8 || ldx < C || ldk % 8 || ldvt % 8 || ldo % 8 || ldvt < Lk) return -1;
     if (((uintptr_t)wq_bias & 15) || ((uintptr_t)wq_wsum & 15) || ((uintptr_t)wq & 15)) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);

@@ -35,7 +35,7 @@ struct GemmArgs {
     float* ws;
     int act;    // PCDM_ACT_*: applied to (acc + bias + rowvec), before the residual add
     int zero_rows;  // linear only: A rows < zero_rows are all-zero and are never read (tiles entirely inside skip their main loop)
-    const float* ln_wsum;    // rowgemm only: the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
+    const float* ln_wsum;    // rowgemm tiles and gemm_ext.hip (EXT 1 / 2): the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
     float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
     const float* ln_row_stats;   // folded LayerNorm, tiled instances (gemm_ext.hip): [M][K / 32][2] partial {sum, M2} of the A rows, written by their producer
     float* gn_stats_out;         // GroupNorm-statistics producer instances (EXT = 4): [tiles_m][2][N / gn_stats_gs][2] {sum, sum of squares}

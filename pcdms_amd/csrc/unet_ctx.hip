@@ -180,7 +180,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         int conv = 0, B = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, stride = 1, upsample = 0;
         int zero_rows = 0;
         int64_t ldo = 0;   // 0: N (GEGLU / NCHW: N)
-        const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles only)
+        const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles, or the tiled kernel with in-kernel statistics / producer partials)
         float ln_eps = 0.f;
         int dup_rows = 0;   // pcdm_gemm_params.dup_rows
         const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride
