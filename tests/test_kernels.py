@@ -479,6 +479,32 @@ def test_flash_attn(backend, case):
         close(o2, ref, tol=1.5e-2)
 
 
+def test_flash_attn_strided_output(backend):
+    """The output epilogue writes whole rows of `out` through LDS (16-byte stores): with `out` a column window of a wider buffer and a ragged
+    query count, the bytes either side of the window and the rows of the next batch stay untouched, the window is bit-identical to the
+    contiguous call; a row stride that is not a multiple of 8 elements is refused (pcdm.h: -1)."""
+    dev = backend.device
+    B, H, Lq, Lk = (2, 1, 37, 66) if backend.is_emu else (2, 5, 1003, 258)
+    Cc = H * 64
+    q, k, v = rnd(B * Lq, Cc, seed=170), rnd(B * Lk, Cc, seed=171), rnd(B * Lk, Cc, seed=172)
+    Lp = (Lk + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, Lp, dtype=BF16)
+    vt[:, :, :Lk] = v.view(B, Lk, Cc).permute(0, 2, 1)
+    qd, kd, vtd = q.to(dev), k.to(dev), vt.to(dev)
+    ref = torch.empty(B * Lq, Cc, dtype=BF16, device=dev)
+    ops.flash_attn(qd, kd, vtd, ref, B, H, Lq, Lk)
+    wide = torch.full((B * Lq, Cc + 16), 7.0, dtype=BF16, device=dev)
+    ops.flash_attn(qd, kd, vtd, wide[:, 8:8 + Cc], B, H, Lq, Lk)
+    backend.sync()
+    w = wide.cpu()
+    assert torch.equal(w[:, 8:8 + Cc], ref.cpu())
+    assert (w[:, :8] == 7.0).all() and (w[:, 8 + Cc:] == 7.0).all()
+    close(ref, _attn_ref(q, k, v, B, H, Lq, Lk), tol=1.5e-2)
+    odd = torch.empty(B * Lq, Cc + 4, dtype=BF16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.flash_attn(qd, kd, vtd, odd[:, :Cc], B, H, Lq, Lk)
+
+
 @pytest.mark.parametrize("case", ["level0", "level1", "level2", "plain"])
 def test_flash_attn_qproj(backend, case):
     """Cross-attention with ``LayerNorm -> to_q`` inside the attention kernel (round 5, pcdm_flash_attn_qproj): against the composition it
