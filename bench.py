@@ -54,7 +54,19 @@ def main():
     ap.add_argument("--no-configs2", action="store_true", help="at --gpus 8: skip the extra batch-8-per-GPU (configs[2]) measurement")
     ap.add_argument("--attn", choices=("bf16", "fp8"), default="bf16",
                     help="fp8 = BASELINE.json configs[4]: e4m3 attention operands on the MX-scaled fp8 MFMA (looser parity; NOT the headline)")
+    # ---- crash-proofing of the world > 1 code path where no multi-GPU node exists (tests/test_bench_contract.py; never a measurement):
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="process-group backend; gloo only together with --emu")
+    ap.add_argument("--emu", action="store_true", help="TEST HOOK: CPU tensors through the lane emulator build of the same kernel sources "
+                                                       "(tests/emu), no GPU, no hipGraph -- executes this file's multi-rank plumbing, measures nothing")
+    ap.add_argument("--tiny", action="store_true", help="the tiny UNet configuration of the CPU suite (same topology) instead of the 868.9 M one")
+    ap.add_argument("--device-weights", action="store_true", help="draw the weights as the world > 1 ranks do (device_state_dict) also at world 1")
+    ap.add_argument("--pair-seed", type=int, default=None, help="seed of this process's pair (default 1000 + rank)")
+    ap.add_argument("--configs2-world", type=int, default=8, help="world size at which BASELINE configs[2]'s own per-GPU batch is also timed")
+    ap.add_argument("--configs2-batch", type=int, default=8)
+    ap.add_argument("--dump", default=None, help="directory: every rank writes rank<r>.pt (its final latents, the gathered tensor, a hash of its weights)")
     args = ap.parse_args()
+    if args.emu != (args.backend == "gloo"):
+        raise SystemExit("--emu and --backend gloo go together (the product path is RCCL on GPUs)")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher (one process per GPU, rendezvous on 127.0.0.1); rank 0's
@@ -80,10 +92,24 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if args.emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.emu:
+        from pcdms_amd import _lib
+        from tests.emu import build_emu
+        _lib.use_library(build_emu.load())
+        dev = torch.device("cpu")
+        args.no_graph = True
+    else:
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     from oracle.pipeline import synth_inputs           # seeded synthetic inputs (data only)
     from oracle.unet import UNetConfig, synth_state_dict
@@ -92,27 +118,28 @@ def main():
     from pcdms_amd.schedulers import DDIMScheduler
     from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
 
-    cfg = UNetConfig()
+    cfg = UNetConfig.tiny() if args.tiny else UNetConfig()
     h, w = args.height // 8, 2 * args.width // 8
     N = args.batch
     t0 = time.time()
     # N = 1: the CPU-seeded weights the parity tests and the cpu_baseline leg use.  N > 1: every rank would spend ~15 s x N of shared
     # host cores on 869 M host random numbers; the ranks draw the same distribution on their GPU instead (same seeds => the same
     # replicated weights on every rank)
-    sd = synth_state_dict(cfg, seed=0) if world == 1 else device_state_dict(cfg, 0, dev)
+    sd = synth_state_dict(cfg, seed=0) if world == 1 and not args.device_weights else device_state_dict(cfg, 0, dev)
     unet = Stage2_InapintUNet2DConditionModel(
         in_channels=9, block_out_channels=cfg.block_out_channels, attention_head_dim=cfg.attention_head_dim,
-        cross_attention_dim=1024, use_linear_projection=True, class_embed_type="projection",
-        projection_class_embeddings_input_dim=1024, sample_size=64)
+        cross_attention_dim=cfg.cross_attention_dim, use_linear_projection=True, class_embed_type="projection",
+        projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim, sample_size=64)
     unet.load_state_dict(sd)
     unet.to(dev)
     unet.set_attention_precision(args.attn)
     sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                           clip_sample=False, set_alpha_to_one=False, steps_offset=1)  # notebook cell 15
     pipe = Stage2_InpaintDiffusionPipeline(unet, sched)
-    inp = synth_inputs(cfg, h, w, N)
+    synth_kw = dict(L_img=4) if args.tiny else {}
+    inp = synth_inputs(cfg, h, w, N, **synth_kw)
     # per-rank pair: different seeded latents / conditioning per rank (data parallel over pairs)
-    g = torch.Generator().manual_seed(1000 + rank)
+    g = torch.Generator().manual_seed(args.pair_seed if args.pair_seed is not None else 1000 + rank)
     inp["latents"] = torch.randn(inp["latents"].shape, generator=g)
     dinp = {k: v.to(dev) for k, v in inp.items()}
     setup_s = time.time() - t0
@@ -127,30 +154,43 @@ def main():
                        pred_t_img_embed=dinp["pred_t_img_embed"], latents=dinp["latents"], num_images_per_prompt=n_img,
                        guidance_scale=2.0, num_inference_steps=args.ddim_steps, output_type="latent",
                        use_graph=not args.no_graph).latents
-            if use_dist:
+            if use_dist and args.backend == "nccl":
                 dist.all_gather_into_tensor(gathered, lat)   # the single collective of the path (RCCL over xGMI)
+            elif use_dist:
+                dist.all_gather(list(gathered.view(world, n_img, 4, h, w).unbind(0)), lat.contiguous())   # (gloo: the CPU test hook)
             return lat
 
         for _ in range(warmup):
             step()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         elapsed = time.perf_counter() - t0
         if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         assert torch.isfinite(out).all()
+        last.update(lat=out.detach().clone(), gathered=None if gathered is None else gathered.clone())
         return elapsed
 
+    last = {}
+
     elapsed = timed(dinp, N, args.steps, args.warmup)
+    if args.dump:
+        import hashlib
+        hsh = hashlib.sha256()
+        for k in sorted(sd):
+            hsh.update(k.encode()); hsh.update(sd[k].detach().float().cpu().numpy().tobytes())
+        Path(args.dump).mkdir(parents=True, exist_ok=True)
+        torch.save({"lat": last["lat"].cpu(), "gathered": None if last["gathered"] is None else last["gathered"].cpu(), "sd_hash": hsh.hexdigest(),
+                    "rank": rank, "world": world}, Path(args.dump) / f"rank{rank}.pt")
     images = world * N * args.steps
     value = images / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -160,7 +200,7 @@ def main():
         "metric": "images/sec (50-step DDIM, 352x512 stage2)", "value": round(value, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.attn == "bf16" else "bf16 (attention: fp8 e4m3)",
-        "data": "synthetic",
+        "data": "synthetic" if not args.emu else "synthetic (LANE EMULATOR on CPU: a plumbing test of the multi-rank path, not a measurement)",
         "config": {"workload": f"stage2 inpaint, {args.width}x{args.height} (canvas {2 * args.width}x{args.height}, "
                                f"latent {h}x{w}), batch={N} per GPU, {args.ddim_steps} DDIM steps, guidance 2.0 (UNet batch {2 * N}), "
                                "868.9M-param UNet, 258 context tokens, bf16 MFMA / fp32 accumulate",
@@ -174,14 +214,17 @@ def main():
                                  "per call instead of once per step, and the all-zero-context CFG half of every cross-attention "
                                  "(LN2, to_q, QK^T/PV, to_out contraction) is skipped (output == to_out.bias exactly)"},
     }
-    if world == 8 and N != 8 and not args.no_configs2:
+    N8 = args.configs2_batch
+    if world == args.configs2_world and world > 1 and N != N8 and not args.no_configs2:
         # BASELINE.json configs[2] as written: batch 64 over 8 GPUs = 8 images (UNet batch 16) per GPU; same protocol
-        inp8 = synth_inputs(cfg, h, w, 8)
+        inp8 = synth_inputs(cfg, h, w, N8, **synth_kw)
         inp8["latents"] = torch.randn(inp8["latents"].shape, generator=torch.Generator().manual_seed(2000 + rank))
-        el8 = timed({k: v.to(dev) for k, v in inp8.items()}, 8, args.steps, max(1, args.warmup))
-        result["config"]["configs2"] = {"workload": "stage2 inpaint, 352x512, batch=64 (8 per GPU, UNet batch 16), 50 DDIM steps, dp8",
-                                        "value": round(world * 8 * args.steps / el8, 4), "unit": "images/s",
+        el8 = timed({k: v.to(dev) for k, v in inp8.items()}, N8, args.steps, args.warmup if args.no_graph else max(1, args.warmup))
+        result["config"]["configs2"] = {"workload": f"stage2 inpaint, 352x512, batch={world * N8} ({N8} per GPU, UNet batch {2 * N8}), {args.ddim_steps} DDIM steps, dp{world}",
+                                        "value": round(world * N8 * args.steps / el8, 4), "unit": "images/s",
                                         "ms_per_step": round(el8 / args.steps * 1e3, 3)}
+        if args.dump:
+            torch.save({"lat": last["lat"].cpu(), "gathered": last["gathered"].cpu()}, Path(args.dump) / f"rank{rank}_configs2.pt")
         timed(dinp, N, 1, 0)   # every rank: back to the headline workload's captured state (kernel_roofline re-runs single steps of it)
 
     if rank == 0 and not args.no_vae:

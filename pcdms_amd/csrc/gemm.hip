@@ -69,6 +69,13 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         // 16x16x32 fragments: wave tile 96x80.  192-row tiles: M = 45056 -> 235 workgroups (N = 320), M = 11264 -> 59 x 2 (N = 640),
         // M = 2816 -> 15 x 4 (N = 1280); 96-row tiles: M = 11264 -> 118 x 2 = 236 -- all within 8 % of the 256 CUs.
         case 21: return launch_gemm<192, 320, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves, 128 KiB, 1 block / CU
+        // Round 6 -- 176-row tiles: 45056 = 256 x 176, 11264 = 64 x 176, 2816 = 16 x 176, 704 = 4 x 176: every level of the 64 x 88 latent
+        // (5632 = 32 x 176 rows per image) divides into 176-row tiles, so M tiles x N tiles x split-K lands on the 256 CUs EXACTLY where the
+        // 192-row tiles give 235 / 236 / 240 workgroups of 9 % more rows each.  176 = 11 fragment rows of 16: the first wave row takes 6 (96
+        // pixels), the second 5 (80) -- its own instance of the K loop (gemm_kernel.inc UNEVEN); waves w and w + 4 share a SIMD, so every SIMD
+        // carries 6 + 5.  Same LDS (the A stage keeps 192 row slots, 16 of them never fetched), same registers, same schedule as 21 / 26.
+        case 22: return launch_gemm<176, 320, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves, 128 KiB, 1 block / CU
+        case 23: return launch_gemm<176, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96|80 x 64: GEGLU-capable), 112 KiB
         // (measured and dropped, never selected by the tuner: 128x320 / 4 waves; 96x320 / 4 waves of 96x80 with two or three stages;
         //  128x160 / 2 waves with three stages)
         case 26: return launch_gemm<192, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96x64 each: GEGLU-capable), 112 KiB
@@ -178,7 +185,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         if (p->epilogue != PCDM_EPI_STORE && p->epilogue != PCDM_EPI_GEGLU && p->epilogue != PCDM_EPI_SPLIT_VT) return -1;
         if (p->epilogue == PCDM_EPI_SPLIT_VT && (p->vt_col0 % 64 || p->rows_per_batch % 32 || (p->ldo2 & 7) || p->M % 32)) return -1;
         if (p->epilogue == PCDM_EPI_GEGLU && (tile == 2 || tile == 8)) return -1;   // (GEGLU pairs need a 64-wide wave tile)
-        if (((tile == 4 || tile == 7 || tile == 18) && p->Npad % 128) || ((tile == 17 || tile == 26) && p->Npad % 256)) return -1;
+        if (((tile == 4 || tile == 7 || tile == 18) && p->Npad % 128) || ((tile == 17 || tile == 26 || tile == 23) && p->Npad % 256)) return -1;
         if (a.ln_row_stats && ((p->K & 63) || p->K > 1280 || ((uintptr_t)a.ln_row_stats & 15))) return -1;   // (16-byte loads of pair couples; <= 40 pairs per row)
         return pcdm_gemm_detail::launch_gemm_ext(a.ln_row_stats ? 2 : 1, tile, a, st);
     }

@@ -37,6 +37,9 @@ int dispatch_ext(int tile, const GemmArgs& a, hipStream_t st) {
         switch (tile) {
             case 17: return launch_gemm<256, 256, 2, 4, 2, false, false, 32, 64, EXT>(a, st);
             case 26: return launch_gemm<192, 256, 2, 4, 2, false, false, 16, 64, EXT>(a, st);
+            case 23:   // round 6: the 176-row tile (M = 11264 = 64 x 176: level 1's GEGLU projection fills the chip exactly); partials only
+                if constexpr (EXT == 2) return launch_gemm<176, 256, 2, 4, 2, false, false, 16, 64, EXT>(a, st);
+                else return -1;
             default: return -1;
         }
     }

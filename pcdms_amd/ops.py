@@ -459,7 +459,7 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
             return e0.elapsed_time(e1)
         best, best_t = (0, 1), timed(two_launches)
         ref_stats = row_stats_reference(a) if (row_stats is not None and pw.K != 320 and pw.K % 64 == 0 and pw.K <= 1280) else None   # (a caller that has a producer)
-        for t in (ROWGEMM_TILES if pw.K == 320 else ()) + LN_TILED_TILES:
+        for t in (ROWGEMM_TILES if pw.K == 320 else ()) + LN_TILED_TILES + LN_PARTIALS_TILES:
             for md in (1, 2):
                 st_ = None if md == 1 else ref_stats
                 if (md == 2 and (st_ is None or t in ROWGEMM_TILES)) or fused(t, st_) != 0:   # (the library refuses what a tile cannot do: Npad not a
@@ -502,11 +502,12 @@ _STATS_VALID: dict = {}
 LN_TILED = os.environ.get("PCDM_LN_TILED", "1") != "0"
 LN_TILED_TILES = (18, 4, 7, 17, 26, 8, 2)   # gemm.hip dispatch_tile_ln(): the tiled instances that take a folded LayerNorm (any K; row statistics
 #                                             from the A tiles as they pass through LDS) -- levels 1-3 of the UNet, the prior, the encoders
+LN_PARTIALS_TILES = (23,)                     # consumers of producer partials only (mode 2; round 6: the 176-row GEGLU-capable tile)
 # gemm.hip dispatch_tile(): id -> (BM, BN)
 TILE_SHAPES = {1: (256, 128), 2: (64, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 64), 7: (128, 128),
                8: (64, 64), 9: (256, 128), 10: (128, 64), 11: (256, 128), 12: (256, 64), 13: (256, 64), 14: (256, 64),
                15: (128, 64), 16: (512, 64), 17: (256, 256), 18: (128, 128),
-               21: (192, 320), 26: (192, 256),
+               21: (192, 320), 26: (192, 256), 22: (176, 320), 23: (176, 256),
                31: (192, 128), 32: (192, 64), 33: (96, 128), 34: (192, 64), 35: (128, 64), 36: (64, 64)}
 _TUNED: dict = {}
 _WS: dict = {}

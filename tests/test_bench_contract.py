@@ -89,6 +89,64 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def _run_bench(args, timeout=900):
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PCDM_BENCH_FORCE_DIST")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+_EMU_FLAGS = ["--backend", "gloo", "--emu", "--tiny", "--batch", "1", "--height", "64", "--width", "32", "--ddim-steps", "1", "--steps", "1", "--warmup", "0",
+              "--no-cpu-baseline", "--no-roofline", "--no-vae"]
+
+
+def test_bench_world2_through_its_own_launcher_on_the_emulator(tmp_path):
+    """The code that will run on the 8-GPU node, executed with MORE THAN ONE RANK before the driver does: a bare
+    ``python bench.py --gpus 2`` becomes the launcher (no monkeypatch: real ``torch.distributed.run`` children on 127.0.0.1), every rank draws
+    its replicated weights with ``device_state_dict``, samples its own pair, the final latents are gathered, the timed region is bracketed by
+    barriers + a MAX all-reduce, and -- with ``--configs2-world 2`` -- the branch that times BASELINE configs[2]'s own per-GPU batch runs too.
+    Here the process group is gloo and the kernels are the lane-emulator build of the same sources (tiny UNet, one DDIM step): a plumbing
+    test, no measurement.  Checked: ONE JSON line; world size 2 in it; both ranks hold identical weights; the gathered tensor is identical
+    on both ranks, and its r-th slice equals a SINGLE-process run of the same file with pair seed 1000 + r (same device-drawn weights)."""
+    import torch
+    d2 = tmp_path / "w2"
+    lines = _run_bench(["--gpus", "2", *_EMU_FLAGS, "--configs2-world", "2", "--configs2-batch", "2", "--dump", str(d2)])
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world_size"] == 2 and d["config"]["process_group"] == "gloo" and d["config"]["global_batch"] == 2
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0 and "EMULATOR" in d["data"]
+    c2 = d["config"]["configs2"]
+    assert c2["value"] > 0 and "batch=4 (2 per GPU" in c2["workload"] and "dp2" in c2["workload"]
+    r0, r1 = torch.load(d2 / "rank0.pt"), torch.load(d2 / "rank1.pt")
+    assert r0["world"] == r1["world"] == 2 and r0["sd_hash"] == r1["sd_hash"]
+    assert torch.equal(r0["gathered"], r1["gathered"]) and r0["gathered"].shape[0] == 2
+    assert torch.equal(r0["gathered"][0:1], r0["lat"]) and torch.equal(r0["gathered"][1:2], r1["lat"])
+    assert not torch.equal(r0["lat"], r1["lat"])                      # two different pairs
+    g0, g1 = torch.load(d2 / "rank0_configs2.pt"), torch.load(d2 / "rank1_configs2.pt")
+    assert torch.equal(g0["gathered"], g1["gathered"]) and g0["gathered"].shape[0] == 4 and torch.equal(g0["gathered"][2:4], g1["lat"])
+    # single-process runs of the same file, one per pair seed
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(2) as ex:
+        futs = [ex.submit(_run_bench, ["--gpus", "1", *_EMU_FLAGS, "--device-weights", "--pair-seed", str(1000 + r), "--dump", str(tmp_path / f"s{r}")])
+                for r in range(2)]
+        for f in futs:
+            assert len(f.result()) == 1
+    for r in range(2):
+        s = torch.load(tmp_path / f"s{r}" / "rank0.pt")
+        assert s["sd_hash"] == r0["sd_hash"] and s["world"] == 1 and s["gathered"] is None
+        assert torch.equal(s["lat"], r0["gathered"][r:r + 1]), r
+
+
+def test_bench_refuses_the_emulator_without_gloo_and_a_world_mismatch():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--emu"], capture_output=True, text=True, timeout=120, cwd=str(ROOT))
+    assert r.returncode != 0 and "go together" in (r.stderr + r.stdout)
+
+
 def test_entry_points_exist():
     src = (ROOT / "__graft_entry__.py").read_text()
     assert "def build(" in src and "def smoke(" in src and "gfx950" in (ROOT / "pcdms_amd" / "build.py").read_text()

@@ -779,6 +779,132 @@ def test_gemm_full_row_tiles_and_zero_rows(backend):
         close(out.view(B, H, W, Cout), refc)
 
 
+def test_gemm_uneven_176_row_tiles(backend):
+    """Round 6: the 176-row block tiles (22 = 176 x 320, 23 = 176 x 256; wave rows of 6 + 5 fragment rows, gemm_kernel.inc UNEVEN) -- 45056 =
+    256 x 176, so the level-0 launches fill the 256 CUs exactly.  Same fragments, same K order as tiles 21 / 26: the outputs must be
+    BIT-IDENTICAL to theirs (and within tolerance of fp32).  Linear with bias / row vector / residual over several M tiles and an M tail, the
+    two-source concat, ``zero_rows``, split-K, GEGLU (tile 23), the 3x3 convolution with halo / stride 2 / nearest-x2 / ``dup_rows``.  The
+    rows a tile must NOT write (the five-fragment wave row's sixth fragment = the next tile's first 16 rows) are checked with an in-place
+    residual: a second write of a row would add its bias twice."""
+    dev = backend.device
+    M, K, N = (176 * 2 + 100, 128, 320) if backend.is_emu else (176 * 70 + 100, 640, 640)
+    a = rnd(M, K, seed=160)
+    w = rnd(N, K, seed=161, scale=1 / math.sqrt(K))
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(162))
+    res = rnd(M, N, seed=163)
+    rpb = M // 2
+    rowvec = torch.randn(2, N, generator=torch.Generator().manual_seed(164))
+    pw = ops.pack_linear(w.float(), bias, dev)
+    ref = a.float() @ w.float().t() + bias + res.float() + rowvec.repeat_interleave(rpb, 0)
+    outs = {}
+    for tile in (21, 22):
+        out = torch.full((M + 40, N), 7.0, dtype=BF16, device=dev)     # 40 guard rows behind the tensor
+        ops.gemm(a.to(dev), pw, out[:M], rowvec=rowvec.to(dev), rows_per_batch=rpb, residual=res.to(dev), res_mod=M, tile=tile)
+        backend.sync()
+        close(out[:M], ref)
+        assert (out[M:] == 7.0).all(), tile
+        outs[tile] = out[:M].clone()
+    assert torch.equal(outs[21], outs[22])
+    # in place (out is the residual): every row written exactly once
+    for tile in (22, 23):
+        if pw.Npad % ops.TILE_SHAPES[tile][1]:
+            continue
+        io = res.clone().to(dev)
+        ops.gemm(a.to(dev), pw, io, residual=io, res_mod=M, tile=tile)
+        backend.sync()
+        close(io, a.float() @ w.float().t() + bias + res.float())
+    # two-source concat + zero_rows (tiles entirely inside skip their K loop)
+    K1 = K // 2
+    z = 176 + 50
+    ag = a.clone()
+    ag[:z] = float("nan")
+    az = a.float().clone()
+    az[:z] = 0
+    got = {}
+    for tile in (21, 22):
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.gemm(ag[:, :K1].contiguous().to(dev), pw, out, a2=ag[:, K1:].contiguous().to(dev), residual=res.to(dev), res_mod=M, tile=tile, zero_rows=z)
+        backend.sync()
+        close(out, az @ w.float().t() + bias + res.float())
+        got[tile] = out.clone()
+    assert torch.equal(got[21], got[22])
+    # split-K (raw fp32 slabs + reduce): the ghost fragment rows must not reach the slabs of the next tile either
+    Ms, Ks, Ns = (176 + 60, 512, 320) if backend.is_emu else (704, 11520, 1280)
+    a2, w2 = rnd(Ms, Ks, seed=165), rnd(Ns, Ks, seed=166, scale=1 / math.sqrt(Ks))
+    pw2 = ops.pack_linear(w2.float(), None, dev)
+    got = {}
+    for tile, sk in ((21, 4), (22, 4), (22, 3), (23, 2)):
+        if pw2.Npad % ops.TILE_SHAPES[tile][1]:
+            continue
+        out = torch.empty(Ms, Ns, dtype=BF16, device=dev)
+        ops.gemm(a2.to(dev), pw2, out, tile=tile, split_k=sk)
+        backend.sync()
+        close(out, a2.float() @ w2.float().t())
+        got[(tile, sk)] = out.clone()
+    assert torch.equal(got[(21, 4)], got[(22, 4)])
+    # GEGLU on the 64-wide wave tiles: 23 against 26
+    Mg, Kg, Ng = (176 + 30, 64, 128) if backend.is_emu else (176 * 33 + 8, 320, 1280)
+    ag_ = rnd(Mg, Kg, seed=167)
+    wg = rnd(2 * Ng, Kg, seed=168, scale=1 / math.sqrt(Kg))
+    bg = torch.randn(2 * Ng, generator=torch.Generator().manual_seed(169))
+    pg = ops.pack_geglu(wg.float(), bg, dev)
+    pr = ag_.float() @ wg.float().t() + bg
+    refg = pr[:, :Ng] * F.gelu(pr[:, Ng:])
+    got = {}
+    for tile in (26, 23):
+        if pg.Npad % ops.TILE_SHAPES[tile][1]:
+            continue
+        out = torch.empty(Mg, Ng, dtype=BF16, device=dev)
+        ops.gemm(ag_.to(dev), pg, out, epilogue=ops.EPI_GEGLU, tile=tile)
+        backend.sync()
+        close(out, refg)
+        got[tile] = out.clone()
+    if len(got) == 2:
+        assert torch.equal(got[26], got[23])
+    # the q | k | v^T epilogue is refused (whole 32-token passes only), not mis-executed
+    Tq = 32
+    xq = rnd(2 * Tq, 64, seed=170)
+    pwq = ops.pack_linear(rnd(3 * 320, 64, seed=171).float(), None, dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(xq.to(dev), pwq, torch.empty(2 * Tq, 640, dtype=BF16, device=dev), rows_per_batch=Tq, epilogue=ops.EPI_SPLIT_VT,
+                 out2=torch.zeros(2, 320, Tq, dtype=BF16, device=dev), vt_col0=640, tile=22)
+    # 3x3 convolutions: halo + M tail, stride 2, nearest-x2 upsample, dup_rows with per-half row vectors and residuals
+    B, H, W, Cin, Cout = (2, 13, 9, 64, 320) if backend.is_emu else (3, 30, 44, 640, 320)
+    xc = rnd(B, Cin, H, W, seed=172)
+    wc = rnd(Cout, Cin, 3, 3, seed=173, scale=1 / math.sqrt(9 * Cin))
+    bc = torch.randn(Cout, generator=torch.Generator().manual_seed(174))
+    pwc = ops.pack_conv3x3(wc.float(), bc, dev)
+    xh = xc.permute(0, 2, 3, 1).contiguous().to(dev)
+    for name, kw, refc in (
+            ("s1", dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), F.conv2d(xc.float(), wc.float(), bc, padding=1)),
+            ("s2", dict(B=B, Hi=H, Wi=W, Ho=(H + 1) // 2, Wo=(W + 1) // 2, stride=2), F.conv2d(xc.float(), wc.float(), bc, padding=1, stride=2)),
+            ("up", dict(B=B, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, upsample=1),
+             F.conv2d(F.interpolate(xc.float(), scale_factor=2.0, mode="nearest"), wc.float(), bc, padding=1))):
+        got = {}
+        for tile in (21, 22):
+            Mo = B * kw["Ho"] * kw["Wo"]
+            out = torch.empty(Mo, Cout, dtype=BF16, device=dev)
+            ops.gemm(xh, pwc, out, conv=kw, tile=tile)
+            backend.sync()
+            close(out.view(B, kw["Ho"], kw["Wo"], Cout), refc.permute(0, 2, 3, 1))
+            got[tile] = out.clone()
+        assert torch.equal(got[21], got[22]), name
+    Mo = B * H * W
+    rv2 = torch.randn(2 * B, Cout, generator=torch.Generator().manual_seed(175))
+    res2 = rnd(2 * Mo, Cout, seed=176)
+    base = F.conv2d(xc.float(), wc.float(), bc, padding=1).permute(0, 2, 3, 1).reshape(Mo, Cout)
+    refd = torch.cat([base, base]) + rv2.repeat_interleave(H * W, 0) + res2.float()
+    got = {}
+    for tile in (21, 22):
+        out = torch.empty(2 * Mo, Cout, dtype=BF16, device=dev)
+        ops.gemm(xh, pwc, out, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), rowvec=rv2.to(dev), rows_per_batch=H * W, residual=res2.to(dev),
+                 res_mod=2 * Mo, tile=tile, dup_rows=Mo)
+        backend.sync()
+        close(out, refd)
+        got[tile] = out.clone()
+    assert torch.equal(got[21], got[22])
+
+
 def test_rowgemm_thin_k(backend):
     """rowgemm.hip (tiles 31..34; 34 = four waves, two workgroups per CU, N tiles split over gridDim.y): the K = 320 GEMM with the activation rows stationary in registers and the weights streamed through one
     LDS ring across all N tiles -- bias + residual store (with an M tail and ``zero_rows``), GEGLU, the q|k / V^T split epilogue, and
@@ -988,11 +1114,11 @@ def test_gemm_row_stats_producer_and_consumer(backend):
             assert (got[..., 1] - want[..., 1]).abs().max() <= 1e-3 * want[..., 1].abs().max() + 1e-3, ptile
         # ---- consumer on the last producer's tensor + partials
         ref = F.layer_norm(t.cpu().double(), (C,), gamma.double(), beta.double(), 1e-5) @ w1.double().t() + b1.double()
-        for ctile in (18, 4, 7, 8, 2, 17, 26):
+        for ctile in (18, 4, 7, 8, 2, 17, 26) + ops.LN_PARTIALS_TILES:
             if pw1.Npad % ops.TILE_SHAPES[ctile][1]:
                 continue
             outs = []
-            for st in (stats, None):
+            for st in (stats, None) if ctile not in ops.LN_PARTIALS_TILES else (stats, stats):   # (tile 23: the partials form only)
                 out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
                 ops.gemm(t, pw1, out, tile=ctile, ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, C, dtype=BF16, device=dev),
                          pw_ln=pw1_ln, row_stats=st)
@@ -1000,6 +1126,24 @@ def test_gemm_row_stats_producer_and_consumer(backend):
                 close(out, ref)
                 outs.append(out.float().cpu())
             assert (outs[0] - outs[1]).abs().max() <= 2e-2 * ref.abs().max(), ctile     # partials vs in-loop statistics: same numbers, other order
+        # ---- GEGLU through the partials form on the 64-wide full-row tiles (round 6: tile 23 = 176 x 256 carries level 1's projection)
+        D = N // 2
+        wg = rnd(2 * D, C, seed=394, scale=1 / math.sqrt(C))
+        bg = torch.randn(2 * D, generator=g) * 0.5
+        pg, pg_ln = ops.pack_geglu(wg.float(), bg, dev), ops.pack_geglu_ln(wg.float(), bg, gamma, beta, dev)
+        hh, gt = (F.layer_norm(t.cpu().double(), (C,), gamma.double(), beta.double(), 1e-5) @ wg.double().t() + bg.double()).chunk(2, -1)
+        got = {}
+        for ctile in (26, 23):
+            if pg.Npad % ops.TILE_SHAPES[ctile][1]:
+                continue
+            out = torch.full((M, D), float("nan"), dtype=BF16, device=dev)
+            ops.gemm(t, pg, out, epilogue=ops.EPI_GEGLU, tile=ctile, ln=(gamma.to(dev), beta.to(dev), 1e-5), ln_buf=torch.empty(M, C, dtype=BF16, device=dev),
+                     pw_ln=pg_ln, row_stats=stats)
+            backend.sync()
+            close(out, hh * F.gelu(gt))
+            got[ctile] = out.clone()
+        if len(got) == 2:
+            assert torch.equal(got[26], got[23])
     # a configuration without a producer instance leaves the buffer alone and says so
     st2 = torch.zeros(M, C // 32, 2, dtype=torch.float32, device=dev)
     ops.gemm(x.to(dev), pw0, t, tile=21 if pw0.Npad % 320 == 0 else 1, row_stats=st2) if pw0.Npad % 128 == 0 else None

@@ -23,11 +23,11 @@ dev = torch.device("cuda:0")
 def run(name, fn_of_tile, flops, tiles):
     for tile in tiles:
         row = []
-        for dbg in (0, 1, 2, 3):
+        for dbg in (0, 1, 2, 3, 8, 16):   # (8 / 16, round 6: steady state without the A / the B loads -- which operand's staging is exposed?)
             t = timeit(lambda: fn_of_tile(tile | (dbg << 8)), iters=10, warmup=2)
             row.append(t)
         print(f"{name:44s} tile{tile}  full {row[0]*1e6:8.1f} us ({flops/row[0]/1e12:6.1f} TF/s) | noload {row[1]*1e6:8.1f} us "
-              f"({flops/row[1]/1e12:6.1f}) | nomfma {row[2]*1e6:8.1f} us | neither {row[3]*1e6:8.1f} us", flush=True)
+              f"({flops/row[1]/1e12:6.1f}) | nomfma {row[2]*1e6:8.1f} us | neither {row[3]*1e6:8.1f} us | no-A {row[4]*1e6:8.1f} us | no-B {row[5]*1e6:8.1f} us", flush=True)
 
 
 def main():

@@ -16,12 +16,12 @@ from pcdms_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.lib()
 BF16 = torch.bfloat16
-NW = {21: 8, 18: 8, 3: 8, 13: 4, 4: 4, 26: 8, 17: 8, 1: 8, 6: 8, 7: 4, 5: 4, 11: 8, 2: 4, 8: 4, 10: 4}
+NW = {21: 8, 18: 8, 3: 8, 13: 4, 4: 4, 26: 8, 17: 8, 1: 8, 6: 8, 7: 4, 5: 4, 11: 8, 2: 4, 8: 4, 10: 4, 22: 8, 23: 8}
 
 
-def run(M, N, K, tile, residual=True, reps=3):
-    a = torch.randn(M, K, device=dev).to(BF16)
-    w = torch.randn(N, K) / K ** 0.5
+def run(M, N, K, tile, residual=True, reps=3, zeros=False):
+    a = (torch.zeros if zeros else torch.randn)(M, K, device=dev).to(BF16)
+    w = (torch.zeros if zeros else torch.randn)(N, K) / K ** 0.5
     pw = ops.pack_linear(w, torch.randn(N), dev)
     res = torch.randn(M, N, device=dev).to(BF16) if residual else None
     out = torch.empty(M, N, dtype=BF16, device=dev)
@@ -59,13 +59,23 @@ def run(M, N, K, tile, residual=True, reps=3):
     d = [(s[:, i + 1] - s[:, i]).median().item() for i in range(5)]
     tot = (s[:, 5] - s[:, 0]).median().item()
     ghz = span / (t_dbg * 1e3)   # cycles per ns if the whole launch were the span (upper bound on the real clock)
-    print(f"M{M} N{N} K{K} tile {tile} res={residual}: {t_plain:.1f} us ({2*M*N*K/t_plain/1e6:.0f} TF/s); stamped {t_dbg:.1f} us; grid span {span:.0f} ticks; "
+    wall = s[:, 7]
+    ok = wall > 0
+    mhz = ((s[ok, 5] - s[ok, 0]) / wall[ok]).median().item() * 100.0 if ok.any() else float("nan")   # shader cycles per 10 ns tick of the 100 MHz counter
+    print(f"[{'zeros' if zeros else 'N(0,1)'}] effective shader clock {mhz:.0f} MHz | "
+          f"M{M} N{N} K{K} tile {tile} res={residual}: {t_plain:.1f} us ({2*M*N*K/t_plain/1e6:.0f} TF/s); stamped {t_dbg:.1f} us; grid span {span:.0f} ticks; "
           f"per wave median ticks: prologue {d[0]:.0f} | first tile {d[1]:.0f} | main loop {d[2]:.0f} | epilogue {d[3]:.0f} | drain {d[4]:.0f} | total {tot:.0f} "
           f"(span/launch = {ghz:.2f} ticks/ns); entry spread {(s[:, 0].max() - s[:, 0].min()).item():.0f}")
 
 
 if __name__ == "__main__":
     import os
+    if os.environ.get("PCDM_ANATOMY") == "clock":   # round 6: the clock the MFMA-dense launches run at (N(0,1) against all-zero operands)
+        for (M, N, K) in [(45056, 320, 2880), (45056, 320, 5760), (11264, 1280, 5760), (45056, 320, 320), (2816, 1280, 11520)]:
+            for tile in (21, 22):
+                for z in (False, True):
+                    run(M, N, K, tile, False, zeros=z)
+        raise SystemExit(0)
     if os.environ.get("PCDM_ANATOMY") == "small":   # the small-M regime (UNet levels 2 / 3: M = 2816 / 704)
         for (M, N, K) in [(2816, 1280, 1280), (2816, 1280, 5120), (704, 1280, 1280)]:
             for tile in (6, 7, 5, 4, 8, 18, 21):

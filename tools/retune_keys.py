@@ -17,7 +17,7 @@ def main():
     from pcdms_amd import ops
     from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
     from tests.test_unet import _inputs, _kwargs
-    prefixes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+    prefixes = [tuple(int(x) if x.lstrip("-").isdigit() else x for x in a.split(",")) for a in sys.argv[1:]]   # ("ln,11264,5120": the folded-LayerNorm keys)
     old = {k: v for k, v in ops._TUNED.items() if any(k[: len(p)] == p for p in prefixes)}
     for k in old:
         del ops._TUNED[k]
