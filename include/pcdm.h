@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* pcdm_stream_t; /* hipStream_t */
 
-#define PCDM_ABI_VERSION 3   /* what pcdm_version() returns for the library this header belongs to */
+#define PCDM_ABI_VERSION 4   /* what pcdm_version() returns for the library this header belongs to */
 int pcdm_version(void);
 /* 1 only for the test-only CPU lane emulator build (tests/emu); the product .so returns 0. */
 int pcdm_is_emulator(void);
@@ -61,15 +61,11 @@ typedef struct pcdm_gn_splitk_src {
     int64_t ldr;
     void* pre_out;
     int32_t store_pre;
+    int32_t rowvec_step_count;    /* as pcdm_gemm_params.rowvec_step_count / step_error (ABI 4) */
+    int32_t* step_error;
 } pcdm_gn_splitk_src;
 int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* src, const void* x2, int C2, int B, int HW, int groups, float eps,
                           const float* gamma, const float* beta, int fuse_silu, void* y, float* ws, pcdm_stream_t s);
-
-/* GroupNorm(+SiLU) of a tensor whose producer left its group sums (pcdm_gemm_params.gn_stats_out, part_rows = 192 rows per tile): merges the
- * partials of each image (Chan) and normalises in one streaming pass -- no statistics pass, no exchange between workgroups.  x, y [B*HW, C]
- * bf16, C = 320 or 640, HW % 64 == 0.  Same result as pcdm_groupnorm up to the summation order of the statistics. */
-int pcdm_groupnorm_from_stats(const void* x, int C, int B, int HW, int groups, float eps, const float* gamma, const float* beta, int fuse_silu,
-                              void* y, const float* gn_stats, int part_rows, pcdm_stream_t s);
 
 /* ---- K8 LayerNorm  [BasicTransformerBlock.norm1/2/3, diffusers attention.py]  x,y [rows,C] bf16 */
 int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma, const float* beta,
@@ -92,6 +88,8 @@ int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const flo
 enum { PCDM_EPI_STORE = 0, PCDM_EPI_GEGLU = 1, PCDM_EPI_SPLIT_VT = 2, PCDM_EPI_NCHW_F32 = 3 };
 enum { PCDM_ACT_NONE = 0, PCDM_ACT_SILU = 1, PCDM_ACT_GELU = 2 };
 typedef struct pcdm_gemm_params {
+    uint32_t struct_size;  /* = sizeof(pcdm_gemm_params) of the header the HOST was compiled against (ABI 4): a struct of another size -- an older or
+                              newer header -- is refused with -1 before any field behind it is read */
     const void* a;
     const void* a2;
     int64_t lda, lda2;
@@ -119,7 +117,7 @@ typedef struct pcdm_gemm_params {
     int64_t ldw;       /* row stride of W in elements (0 -> K); lets an activation slice act as the [N,K] operand */
     int32_t no_pad_lo; /* conv: 1 = zero padding at the bottom/right only (taps start AT the output pixel): the VAE
                           encoder's Downsample2D(padding=0) + F.pad(0,1,0,1); 0 = symmetric padding 1 */
-    int32_t tile;      /* 0 = heuristic; 1..26 = explicit tile configuration (gemm.hip dispatch_tile), 31..36 = the A-in-registers thin-K
+    int32_t tile;      /* 0 = heuristic; 1..26 = explicit tile configuration (gemm.hip dispatch_tile; 22 / 23 = the 176-row tiles), 31..36 = the A-in-registers thin-K
                           kernel (rowgemm.hip; K = 320, linear); -1 if invalid for the problem */
     int32_t act;       /* PCDM_ACT_*: out = act(acc + bias + rowvec) + residual.  With PCDM_EPI_GEGLU: gate activation, 0 = GELU(erf) (GEGLU),
                           PCDM_ACT_SILU = SwiGLU (DINOv2 SwiGLUFFN).  SiLU: the convs of
@@ -156,19 +154,18 @@ typedef struct pcdm_gemm_params {
                                    rows stored, [M][N / 32][2] fp32, from the bf16-rounded output values (bias / rowvec / residual included).  The
                                    producer of the rows a LayerNorm reads next (Transformer2DModel.proj_in, attn1 / attn2 .to_out + residual).
                                    N % 32 == 0 */
-    float* gn_stats_out;        /* tile 21 + PCDM_EPI_STORE (3x3 convolution or linear; else -1): also write the GROUP sums of the rows stored, for the GroupNorm
-                                   that reads the tensor next: [ceil(M / 192)][2][N / gn_stats_gs][2] fp32 = per 192-row tile and per image it touches
-                                   (slot 0: the image of its first row, slot 1: the next one) {sum, sum of squares} of every group of gn_stats_gs
-                                   channels over the tile's rows of that image, from the bf16-rounded output values.  pcdm_groupnorm_from_stats merges
-                                   them and only normalises.  M % 32 == 0, rows_per_batch % 32 == 0, >= 192, 80 % gn_stats_gs == 0 */
-    int32_t gn_stats_gs;
+    int32_t rowvec_step_count;  /* > 0 with rowvec_step: the number of blocks behind rowvec.  A counter value outside [0, count) is CLAMPED into the table on
+                                   the device (the launch stays inside the caller's memory) and, if step_error is non-NULL, *step_error is set to 1 -- the
+                                   host reads it when it next synchronises (pcdm_unet_step_overflow for the UNet context).  0: unchecked (ABI <= 3 behaviour) */
+    int32_t* step_error;        /* DEVICE int32, written only on an out-of-range step (never cleared by the library) */
 } pcdm_gemm_params;
-/* pcdm_version() == 3: the struct above ends with ln_row_stats, row_stats_out, gn_stats_out, gn_stats_gs (2: ended with dup_rows; 1: with ln_eps).  Zero-initialise it (memset) and build against
- * the header of the library in use: a host compiled against an older header passes a shorter struct.  A host MUST compare
- * pcdm_version() with the PCDM_ABI_VERSION it was compiled against before its first pcdm_gemm call (the library reads the trailing fields
- * unconditionally).  bias, rowvec, ldrv and rowvec_step_stride must keep 16-byte alignment (4 floats): the epilogues load them as
- * float4; a violation returns -1.  *rowvec_step must stay below the number of blocks behind rowvec -- it is device memory the library
- * cannot validate at launch. */
+/* pcdm_version() == 4: the struct above STARTS with struct_size and ends with rowvec_step_count, step_error (3: no struct_size, ended with
+ * ln_row_stats, row_stats_out, gn_stats_out, gn_stats_gs -- the last two are gone with the GroupNorm-statistics producer; 2: ended with
+ * dup_rows; 1: with ln_eps).  Zero-initialise it (memset), set struct_size = sizeof(pcdm_gemm_params): the library compares it with its own and
+ * returns -1 on a mismatch, so a host built against another header fails at its first call instead of having trailing fields misread.
+ * (Comparing pcdm_version() with PCDM_ABI_VERSION at start-up remains good practice: the other entry points have no such guard.)
+ * bias, rowvec, ldrv and rowvec_step_stride must keep 16-byte alignment (4 floats): the epilogues load them as float4; a violation returns -1.
+ * *rowvec_step is device memory the library cannot validate at launch: pass rowvec_step_count to have it bounded on the device. */
 int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s);
 
 /* ---- K9/K10 fused attention (replaces xformers.ops.memory_efficient_attention enabled at
@@ -185,15 +182,6 @@ int pcdm_flash_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, cons
 #define PCDM_ATTN_DEFAULT_THR 8.0f
 int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                         void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s);
-
-/* The cross-attention of a BasicTransformerBlock with its query path inside (norm2 -> attn2.to_q -> attention over the context tokens;
- * /root/reference/src/models/stage2_inpaint_unet_2d_condition.py:321-361 -> diffusers BasicTransformerBlock.attn2): x [B*Lq, ldx] bf16 = the
- * block's token rows (C channels, C % 64 == 0), wq [H*64][C] bf16 + wq_bias / wq_wsum [H*64] fp32 = to_q with the LayerNorm folded in (as
- * pcdm_gemm_params.ln_wsum; wq_wsum NULL: plain projection).  Each workgroup projects its own 128 x 64 query tile (row statistics from the
- * rows it loads), rounds it to bf16 where pcdm_gemm would have stored it, and runs pcdm_flash_attn's loop.  One launch for three. */
-int pcdm_flash_attn_qproj(const void* x, int64_t ldx, int C, const void* wq, const float* wq_bias, const float* wq_wsum, float ln_eps,
-                          const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Lq, int Lk,
-                          float scale, pcdm_stream_t s);
 
 /* ---- N4 (BASELINE.json configs[4]): the same attention with OCP e4m3 operands on the MX-scaled fp8 MFMA (unit block
  *      scales; twice the bf16 matrix rate).  No reference counterpart (attention enters at stage2_batchtest_inpaint_model.py:133).
@@ -338,13 +326,18 @@ int pcdm_unet_set_shared_cfg_input(pcdm_unet* u, void* workspace, int shared);
  * pcdm_unet_forward calls on this workspace that pass the same t_dev and a device step counter pick their block by that counter; any other
  * call computes the embeddings per step as before.  Bit-identical to the per-step launches.  The table is keyed on the POINTER t_dev: a host
  * that rewrites the timestep buffer in place (another schedule or step count) must call pcdm_unet_prepare_timesteps again before the
- * next forward, and the device step counter must stay below n (neither is checkable at launch: both live in device memory). */
+ * next forward (not checkable at launch: it lives in device memory).  The device step counter must stay below n: ABI 4 bounds it on the
+ * device (clamped into the table, error flag: pcdm_unet_step_overflow). */
 int64_t pcdm_unet_time_table_bytes(const pcdm_unet* u, int n, int B);
 int pcdm_unet_prepare_timesteps(pcdm_unet* u, const int64_t* t_dev, int n, void* table, void* workspace, pcdm_stream_t s);
 /* x_in NHWC bf16 [B, h, w, conv_in.cin] (pcdm_assemble_input / pcdm_nchw_f32_to_nhwc_bf16); timestep = t_dev[step_dev ? *step_dev : 0] (device);
  * pose_b as passed to prepare_conditioning (0: no pose); eps_out fp32 NCHW [B, out_channels, h, w] */
 int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* t_dev, const int32_t* step_dev, int B, int h, int w, int L, int pose_b,
                       void* workspace, float* eps_out, pcdm_stream_t s);
+/* Did a pcdm_unet_forward on this workspace ever find *step_dev outside the time table of pcdm_unet_prepare_timesteps (>= n or negative)?  Such a
+ * forward does NOT read out of bounds -- every consumer of the table clamps the step on the device -- but its time embedding is that of the
+ * last table row: *flag_out = 1 then (and stays 1 until pcdm_unet_workspace_init / pcdm_unet_prepare_timesteps clear it).  Synchronises s. */
+int pcdm_unet_step_overflow(pcdm_unet* u, void* workspace, int* flag_out, pcdm_stream_t s);
 /* Host-side weight packing (plain loops on HOST memory; upload the result): the layouts pcdm_gemm / pcdm_unet_set_weight expect, from the
  * fp32 tensors of a diffusers state dict.  Each returns Npad (< 0: bad arguments); output pointers may be NULL to query sizes.
  *   pcdm_pack_linear : [N, K] -> bf16 [Npad, K], bias -> fp32 [Npad]                       (Npad = N rounded up to pad_to, normally 64)

@@ -27,6 +27,7 @@ class GemmParams(C.Structure):
     """Mirror of ``pcdm_gemm_params`` (include/pcdm.h)."""
 
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("a", C.c_void_p), ("a2", C.c_void_p), ("lda", C.c_int64), ("lda2", C.c_int64),
         ("c1", C.c_int32), ("conv", C.c_int32),
         ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
@@ -42,8 +43,12 @@ class GemmParams(C.Structure):
         ("zero_rows", C.c_int32),
         ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
         ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64), ("dup_rows", C.c_int32),
-        ("ln_row_stats", C.c_void_p), ("row_stats_out", C.c_void_p), ("gn_stats_out", C.c_void_p), ("gn_stats_gs", C.c_int32),
+        ("ln_row_stats", C.c_void_p), ("row_stats_out", C.c_void_p), ("rowvec_step_count", C.c_int32), ("step_error", C.c_void_p),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(GemmParams)   # (ABI 4: pcdm_gemm refuses a struct of another size)
 
 
 class GnSplitKSrc(C.Structure):
@@ -51,7 +56,8 @@ class GnSplitKSrc(C.Structure):
 
     _fields_ = [("part", C.c_void_p), ("split_k", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32),
                 ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ldrv", C.c_int64), ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64),
-                ("residual", C.c_void_p), ("ldr", C.c_int64), ("pre_out", C.c_void_p), ("store_pre", C.c_int32)]
+                ("residual", C.c_void_p), ("ldr", C.c_int64), ("pre_out", C.c_void_p), ("store_pre", C.c_int32),
+                ("rowvec_step_count", C.c_int32), ("step_error", C.c_void_p)]
 
 
 class UNetConfig(C.Structure):
@@ -72,11 +78,9 @@ _SIGS = {
     "pcdm_groupnorm": ([_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_groupnorm_splitk": ([C.POINTER(GnSplitKSrc), _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_layernorm": ([_P, _P, _I, _I, _F, _P, _P, _P], C.c_int),
-    "pcdm_groupnorm_from_stats": ([_P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _I, _P], C.c_int),
     "pcdm_gemm": ([C.POINTER(GemmParams), _P], C.c_int),
     "pcdm_flash_attn": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_flash_attn_thr": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _P], C.c_int),
-    "pcdm_flash_attn_qproj": ([_P, _L, _I, _P, _P, _P, _F, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_quantize_fp8": ([_P, _P, _L, _I, _I, _L, _L, _F, _P], C.c_int),
     "pcdm_flash_attn_fp8": ([_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _F, _F, _F, _F, _P], C.c_int),
     "pcdm_timestep_embedding": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
@@ -112,6 +116,7 @@ _SIGS = {
     "pcdm_unet_prepare_timesteps": ([_P, _P, _I, _P, _P, _P], C.c_int),
     "pcdm_unet_set_shared_cfg_input": ([_P, _P, _I], C.c_int),
     "pcdm_unet_forward": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "pcdm_unet_step_overflow": ([_P, _P, C.POINTER(C.c_int), _P], C.c_int),
     "pcdm_pack_linear": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),
     "pcdm_pack_conv3x3": ([_P, _P, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "pcdm_pack_geglu": ([_P, _P, _I, _I, _P, _P], C.c_int),

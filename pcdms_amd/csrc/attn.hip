@@ -46,30 +46,15 @@ constexpr int QPB = 128;   // queries per workgroup
 // ROWSUM_VALU: the softmax denominator as per-lane fp32 adds of the un-rounded P (combined across the two lane halves once, at the
 // end) instead of an MFMA against a ones fragment (4 of the 22 MFMAs per tile); which one wins depends on which pipe has slack.
 // (s_setprio 1 around the two MFMA clusters was measured too: no gain with 3 co-resident waves per SIMD -- removed.)
-// QPROJ (round 5, the cross-attention of BasicTransformerBlock: norm2 -> attn2.to_q -> attention over the 258 context tokens,
-// /root/reference/src/models/stage2_inpaint_unet_2d_condition.py:321-361 -> diffusers Attention): `q` holds the block's TOKEN rows x [B*Lq, C],
-// not projected queries, and the workgroup computes its own Q tile first: Q^T[d, query] = sum_c W'[64 h + d, c] x[query, c] on the matrix
-// pipe straight from global memory / L2 (A operand = the head's 64 rows of the LayerNorm-FOLDED to_q weight, fed in the key-row permutation
-// pi so that the accumulator registers come out as the lane's eight consecutive head dims of the QK^T operand -- no cross-lane exchange;
-// B operand = the lane's own query row), the folded LayerNorm as rstd (acc - mean wsum[d]) + b'[d] with the row statistics taken from the
-// B fragments the lane already holds (shifted sums; its partner lane ^ 32 holds the other half of the row), rounded to bf16 where the
-// projection GEMM would have stored it.  Saves the to_q launch and its round trip through HBM (and the LayerNorm launch in front of it); the
-// x rows are re-read by the H heads (L2), the weight slice by every workgroup of the head (L2).
-struct QProj {
-    const u16* w;        // [H * 64][C] bf16, C contiguous: to_q with the LayerNorm folded in (W diag(gamma))
-    const float* bias;   // [H * 64]: b + W beta
-    const float* wsum;   // [H * 64]: row sums of the bf16 weights; NULL = no LayerNorm (plain projection)
-    int C;               // channels (C % 64 == 0)
-    float eps;
-};
-
-template <bool ROWSUM_VALU, bool QPROJ = false>
+// (Round 5 also measured the cross-attention with its query path inside the kernel -- norm2 -> attn2.to_q on the matrix pipe straight from
+//  global memory in front of the key loop -- 3-40 % SLOWER than the launches it replaced (profiles/r5_bench_xattn.txt); removed in round 6,
+//  the code is in the git history: commit 'cross-attention as one launch'.)
+template <bool ROWSUM_VALU>
 __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restrict__ q, int64_t ldq,
                                                          const u16* __restrict__ k, int64_t ldk,
                                                          const u16* __restrict__ vt, int64_t ldvt,
                                                          u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
-                                                         float c /* scale * log2(e) */, float thr /* lazy-rescale threshold, log2 units */,
-                                                         const QProj qp_args) {
+                                                         float c /* scale * log2(e) */, float thr /* lazy-rescale threshold, log2 units */) {
     // K tile [64 keys][64 d] and V^T tile [64 d][64 keys], 2 stages each, unpadded 128-byte rows whose 16-byte
     // chunks are XOR-swizzled by (row>>1)&7 (applied on the DMA source offset and on the fragment reads, exactly
     // as in gemm.hip): conflict-free ds_read_b128, filled by buffer_load ... lds with no VGPR round trip.
@@ -86,8 +71,8 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
     const bool qvalid = qrow < Lq;
     if (!qvalid) qrow = Lq - 1;
     u16x8 qf[4];
-    const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);  // K row permutation (and the weight-row permutation of QPROJ)
-    if constexpr (!QPROJ) {
+    const int pi = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);  // K row permutation
+    {
         const u16* qp = q + ((int64_t)b * Lq + qrow) * ldq + h * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -95,84 +80,6 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) qf[ks][e] = f2bf(bf2f(raw[e]) * c);   // scores come out of the MFMA in log2 units
         }
-    } else {
-        // ---- Q^T = W' x^T for this wave's 32 queries: two 32-row fragments of head dims, k-steps of 16 channels, operands straight from
-        // global memory with PD k-steps in flight behind the ones being multiplied
-        const int C = qp_args.C;
-        const u16* xp = q + ((int64_t)b * Lq + qrow) * ldq + hh * 8;                           // B: lane -> its query's channels 16 ks + 8 hh ..
-        const u16* wp = qp_args.w + ((int64_t)(h * 64 + pi)) * C + hh * 8;                     // A: MFMA row `col` = head dim pi(col) (+ 32 for the second fragment)
-        constexpr int PD = 4;
-        f32x16 qa[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) qa[0][r] = qa[1][r] = 0.f;
-        float sx = 0.f, sq = 0.f;
-        const float piv = __shfl(bf2f(xp[0]), col, 64);    // the shift of the row sums: the row's first element (held by the lane of half 0)
-        u16x8 xb[2][PD], wa[2][PD][2];
-        const int ng = C / (16 * PD);
-        auto load_group = [&](int gi, auto bsel) {
-            constexpr int bb = decltype(bsel)::value;
-#pragma unroll
-            for (int j = 0; j < PD; ++j) {
-                const int ko = (gi * PD + j) * 16;
-                xb[bb][j] = *(const u16x8*)(xp + ko);
-                wa[bb][j][0] = *(const u16x8*)(wp + ko);
-                wa[bb][j][1] = *(const u16x8*)(wp + (int64_t)32 * C + ko);
-            }
-        };
-        auto mul_group = [&](auto bsel) {
-            constexpr int bb = decltype(bsel)::value;
-#pragma unroll
-            for (int j = 0; j < PD; ++j) {
-                qa[0] = mfma_32x32x16(wa[bb][j][0], xb[bb][j], qa[0]);
-                qa[1] = mfma_32x32x16(wa[bb][j][1], xb[bb][j], qa[1]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = bf2f(xb[bb][j][e]) - piv;
-                    sx += d;
-                    sq += d * d;
-                }
-            }
-        };
-        typedef std::integral_constant<int, 0> G0;
-        typedef std::integral_constant<int, 1> G1;
-        load_group(0, G0());
-        for (int gi = 0; gi < ng; gi += 2) {
-            if (gi + 1 < ng) load_group(gi + 1, G1());
-            mul_group(G0());
-            if (gi + 1 < ng) {
-                if (gi + 2 < ng) load_group(gi + 2, G0());
-                mul_group(G1());
-            }
-        }
-        // the folded LayerNorm: this query's mean / rstd (its other half of the row lives in lane ^ 32)
-        float mean = 0.f, rstd = 1.f;
-        if (qp_args.wsum) {
-            sx += __shfl_xor(sx, 32, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            const float inv_c = 1.0f / (float)C, ds = sx * inv_c;
-            float var = sq * inv_c - ds * ds;
-            var = var > 0.f ? var : 0.f;
-            mean = piv + ds;
-            rstd = 1.0f / sqrtf(var + qp_args.eps);
-        }
-        // accumulator register r of fragment f = head dim 32 f + 16 (r >> 3) + 8 hh + (r & 7) of this lane's query: exactly qf[2 f + (r >> 3)][r & 7]
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int r8 = 0; r8 < 2; ++r8) {
-                const int d0 = h * 64 + 32 * f + 16 * r8 + 8 * hh;
-                f32x4 bv[2], wv[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    bv[i] = qp_args.bias ? *(const f32x4*)(qp_args.bias + d0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    wv[i] = qp_args.wsum ? *(const f32x4*)(qp_args.wsum + d0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float qv = rstd * (qa[f][8 * r8 + e] - mean * wv[e >> 2][e & 3]) + bv[e >> 2][e & 3];
-                    qf[2 * f + r8][e] = f2bf(bf2f(f2bf(qv)) * c);      // bf16 where the projection GEMM would have stored it, then the log2-unit scale
-                }
-            }
     }
 
     // LDS-DMA staging: wave w, instruction j fills rows (2w+j)*8 .. +7 of the K tile and of the V^T tile
@@ -560,28 +467,11 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
 #define PCDM_ATTN_LAUNCH(RS)                                                                                                            \
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS, false>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
-                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2, QProj{})
+    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
+                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2)
     if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true);
     else PCDM_ATTN_LAUNCH(false);
 #undef PCDM_ATTN_LAUNCH
-    PCDM_CHECK_LAUNCH();
-    return 0;
-}
-
-// Cross-attention with the query projection inside (flash_attn_kernel<., QPROJ>): x [B*Lq, ldx] bf16 token rows with C channels; wq [H*64][C]
-// bf16 (K contiguous) with bias / wsum as packed by pcdm_pack_linear with a folded LayerNorm (wsum NULL: plain projection, no LayerNorm)
-extern "C" int pcdm_flash_attn_qproj(const void* x, int64_t ldx, int C, const void* wq, const float* wq_bias, const float* wq_wsum, float ln_eps,
-                                     const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Lq, int Lk,
-                                     float scale, pcdm_stream_t s) {
-    if (!x || !wq || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || C <= 0) return -1;
-    if (C % 64 || ldx % 8 || ldx < C || ldk % 8 || ldvt % 8 || ldo % 8 || ldvt < Lk) return -1;
-    if (((uintptr_t)wq_bias & 15) || ((uintptr_t)wq_wsum & 15) || ((uintptr_t)wq & 15)) return -1;
-    if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
-    const dim3 grid((Lq + QPB - 1) / QPB, H, B);
-    const QProj qp{(const u16*)wq, wq_bias, wq_wsum, C, ln_eps};
-    PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<false, true>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)x, ldx, (const u16*)k, ldk,
-                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, PCDM_ATTN_DEFAULT_THR, qp);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

@@ -92,7 +92,8 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
-    if (!p || !p->a || !p->w || !p->out) return -1;
+    if (!p || p->struct_size != (uint32_t)sizeof(pcdm_gemm_params)) return -1;   // (a host built against another header: refused before any other field is read)
+    if (!p->a || !p->w || !p->out) return -1;
     if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->K % BK || p->Npad % 64 || p->Npad < p->N || p->N % 4) return -1;
     if (p->rows_per_batch <= 0) return -1;
     // 16-byte vector loads of the epilogue operands: bias and rowvec bases, the row pitch and the per-step block stride
@@ -124,6 +125,9 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.rowvec = p->rowvec;
     a.rowvec_step = p->rowvec ? p->rowvec_step : nullptr;
     a.rowvec_step_stride = p->rowvec_step_stride;
+    a.rowvec_step_count = a.rowvec_step ? p->rowvec_step_count : 0;
+    a.step_error = a.rowvec_step ? p->step_error : nullptr;
+    if (a.rowvec_step_count < 0 || ((uintptr_t)a.step_error & 3)) return -1;
     a.ldrv = p->ldrv > 0 ? (int)p->ldrv : p->N;
     a.rows_per_batch = p->rows_per_batch;
     a.residual = (const u16*)p->residual;
@@ -171,6 +175,7 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     int tile = p->tile & 0xff;
     if (tile >= pcdm_gemm_detail::kRowGemmTile0) {
         if ((a.debug & 4) && p->ws_floats < (int64_t)((p->M + 95) / 96) * 8 * 8 * 2) return -1;   // (stamps: 8 x uint64 per wave)
+        if (p->row_stats_out) return -1;   // (the A-in-registers kernel has no partials producer: refused, never silently ignored -- ADVICE r5)
         return p->conv ? -1 : pcdm_gemm_detail::launch_rowgemm(tile, a, st);
     }
     a.ln_row_stats = p->ln_row_stats;
@@ -190,18 +195,6 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         return pcdm_gemm_detail::launch_gemm_ext(a.ln_row_stats ? 2 : 1, tile, a, st);
     }
     if (a.ln_row_stats) return -1;
-    a.gn_stats_out = p->gn_stats_out;
-    a.gn_stats_gs = p->gn_stats_gs;
-    if (a.gn_stats_out) {
-        // GroupNorm-statistics producer (gemm_ext.hip, EXT = 4): a STORE launch on the full-row tile whose lean epilogue also leaves the per-group
-        // sums of the rows it stores.  Whole 32-row passes inside one image, wave column ranges (80) that are whole groups
-        if (tile != 21 || a.split_k > 1 || p->act || a.dup_rows || a.zero_rows || p->epilogue != PCDM_EPI_STORE || (p->N & 7) || (p->ldo & 7) || p->Npad % 320 ||
-            p->M % 32 || p->rows_per_batch % 32 || p->M % p->rows_per_batch || p->rows_per_batch < 192 || a.gn_stats_gs < 8 || 80 % a.gn_stats_gs ||
-            p->N % a.gn_stats_gs || a.row_stats_out || (p->residual && ((p->ldr & 7) || (p->res_mod > 0 && p->res_mod < p->M))))
-            return -1;
-        a.cin = p->conv ? p->cin : 0;   // (launch_gemm_ext tells the convolution from the linear instance by it)
-        return pcdm_gemm_detail::launch_gemm_ext(4, tile, a, st);
-    }
     if (a.row_stats_out) {
         // row-statistics producer (gemm_ext.hip): a linear STORE launch whose lean epilogue also writes the {sum, M2} of every 32-column run of
         // the rows it stores

@@ -19,6 +19,8 @@ struct GemmArgs {
     const float* rowvec;
     const int32_t* rowvec_step;     // device counter selecting the row-vector block: rowvec + *rowvec_step * rowvec_step_stride (pcdm_gemm_params)
     int64_t rowvec_step_stride;
+    int rowvec_step_count;          // > 0: blocks behind rowvec; a counter outside [0, count) is clamped and *step_error set (pcdm_gemm_params, ABI 4)
+    int32_t* step_error;
     int ldrv;
     int rows_per_batch;
     const u16* residual;
@@ -38,8 +40,6 @@ struct GemmArgs {
     const float* ln_wsum;    // rowgemm tiles and gemm_ext.hip (EXT 1 / 2): the weights carry a folded LayerNorm (W diag(gamma), bias + W beta); fp32 [Npad] row sums of
     float ln_eps;            // the folded weights: out = rstd (acc - mean wsum[n]) + bias[n] with the row's own mean / rstd (eps ln_eps)
     const float* ln_row_stats;   // folded LayerNorm, tiled instances (gemm_ext.hip): [M][K / 32][2] partial {sum, M2} of the A rows, written by their producer
-    float* gn_stats_out;         // GroupNorm-statistics producer instances (EXT = 4): [tiles_m][2][N / gn_stats_gs][2] {sum, sum of squares}
-    int gn_stats_gs;             // channels per group
     float* row_stats_out;        // row-statistics producer instances: [M][N / 32][2] partials of the stored rows
     int dup_rows;       // conv, lean epilogue: also write rows m + dup_rows (their own rowvec / residual rows): pcdm_gemm_params.dup_rows
     int defer_reduce;   // split_k > 1: no reduce launch (pcdm_groupnorm_splitk consumes the partial slabs)
@@ -50,8 +50,18 @@ struct GemmArgs {
 
 namespace pcdm_gemm_detail {
 // the row-vector block of this launch (one scalar load when a step counter is given)
+// the device step counter bounded into a table of `count` blocks (count <= 0: unchecked); an out-of-range value is reported through *err
+// (every lane that sees it stores the same 1: a benign race) and the launch reads the nearest valid block instead of foreign memory
+__device__ __forceinline__ int bounded_step(const int32_t* step, int count, int32_t* err) {
+    int st = *step;
+    if (count > 0 && (st < 0 || st >= count)) {
+        if (err) *err = 1;
+        st = st < 0 ? 0 : count - 1;
+    }
+    return st;
+}
 __device__ __forceinline__ const float* rowvec_base(const GemmArgs& p) {
-    return (p.rowvec && p.rowvec_step) ? p.rowvec + (int64_t)(*p.rowvec_step) * p.rowvec_step_stride : p.rowvec;
+    return (p.rowvec && p.rowvec_step) ? p.rowvec + (int64_t)bounded_step(p.rowvec_step, p.rowvec_step_count, p.step_error) * p.rowvec_step_stride : p.rowvec;
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
     return act == PCDM_ACT_SILU ? silu_f(v) : act == PCDM_ACT_GELU ? gelu_erf_f(v) : v;

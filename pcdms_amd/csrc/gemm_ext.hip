@@ -44,20 +44,9 @@ int dispatch_ext(int tile, const GemmArgs& a, hipStream_t st) {
         }
     }
 }
-// EXT = 4: the GroupNorm-statistics producers -- the full-row tile of level 0 (192 x 320, wave tiles 96 x 80: eight whole groups of 10 channels
-// at C = 320, four of 20 at C = 640), as the 3x3 convolution (conv1 -> norm2, conv2 + residual -> Transformer2DModel.norm) and as the linear
-// (proj_out + residual -> the next block's norm1 / conv_norm_out)
-template <bool CONV>
-int dispatch_gns(int tile, const GemmArgs& a, hipStream_t st) {
-    switch (tile) {
-        case 21: return launch_gemm<192, 320, 2, 4, 2, CONV, false, 16, 64, 4>(a, st);
-        default: return -1;
-    }
-}
 }  // namespace
 
 int pcdm_gemm_detail::launch_gemm_ext(int ext, int tile, const GemmArgs& a, hipStream_t st) {
-    if (ext == 4) return a.cin > 0 && a.B > 0 ? dispatch_gns<true>(tile, a, st) : dispatch_gns<false>(tile, a, st);
     switch (ext) {
         case 1: return dispatch_ext<1>(tile, a, st);
         case 2: return dispatch_ext<2>(tile, a, st);

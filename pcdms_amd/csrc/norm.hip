@@ -59,6 +59,8 @@ struct GnSrc {
     const float* rowvec;    // [B][ldrv] or NULL (the time-embedding projection row of the batch entry)
     const int32_t* rowvec_step;   // optional device step counter: block rowvec + *rowvec_step * rowvec_step_stride (pcdm_gemm_params)
     int64_t rowvec_step_stride;
+    int rowvec_step_count;        // > 0: the counter is bounded into [0, count) on the device, *step_error = 1 when it was not (ABI 4)
+    int32_t* step_error;
     int ldrv;
     const u16* residual;    // [M][ldr] or NULL
     int ldr;
@@ -73,7 +75,15 @@ __device__ __forceinline__ u16x8 gn_src_load(const GnSrc& s, int b, int64_t row,
     // operands first (unconditional loads; absent ones read zeros), then the slabs in their fixed order, four in flight at a time
     const f32x4 b0 = *(const f32x4*)(s.bias ? s.bias + c : (const float*)g_gn_zero32);
     const f32x4 b1 = *(const f32x4*)(s.bias ? s.bias + c + 4 : (const float*)g_gn_zero32);
-    const float* rvb = (s.rowvec && s.rowvec_step) ? s.rowvec + (int64_t)(*s.rowvec_step) * s.rowvec_step_stride : s.rowvec;
+    const float* rvb = s.rowvec;
+    if (s.rowvec && s.rowvec_step) {
+        int st = *s.rowvec_step;
+        if (s.rowvec_step_count > 0 && (st < 0 || st >= s.rowvec_step_count)) {   // (as pcdm_gemm_detail::bounded_step)
+            if (s.step_error) *s.step_error = 1;
+            st = st < 0 ? 0 : s.rowvec_step_count - 1;
+        }
+        rvb = s.rowvec + (int64_t)st * s.rowvec_step_stride;
+    }
     const f32x4 t0 = *(const f32x4*)(rvb ? rvb + (int64_t)b * s.ldrv + c : (const float*)g_gn_zero32);
     const f32x4 t1 = *(const f32x4*)(rvb ? rvb + (int64_t)b * s.ldrv + c + 4 : (const float*)g_gn_zero32);
     const u16x8 rv = *(const u16x8*)(s.residual ? s.residual + row * s.ldr + c : (const u16*)g_gn_zero32);
@@ -1002,114 +1012,10 @@ extern "C" int pcdm_groupnorm_splitk(const pcdm_gn_splitk_src* p, const void* x2
     src.part = p->part; src.S = p->split_k; src.ldp = p->Npad; src.slab = (int64_t)p->M * p->Npad;
     src.bias = p->bias; src.rowvec = p->rowvec; src.ldrv = (int)p->ldrv;
     src.rowvec_step = p->rowvec ? p->rowvec_step : nullptr; src.rowvec_step_stride = p->rowvec_step_stride; src.residual = (const u16*)p->residual; src.ldr = (int)p->ldr;
+    src.rowvec_step_count = src.rowvec_step ? p->rowvec_step_count : 0; src.step_error = src.rowvec_step ? p->step_error : nullptr;
+    if (src.rowvec_step_count < 0 || ((uintptr_t)src.step_error & 3)) return -1;
     src.pre_out = p->store_pre ? (u16*)p->pre_out : nullptr;   // (the two-kernel path writes the buffer whatever the flag)
     return gn_launch(src, B, HW, groups, eps, gamma, beta, fuse_silu, y, ws, (hipStream_t)s, (u16*)p->pre_out);
-}
-
-// GroupNorm(+SiLU) of a tensor whose GROUP SUMS its producer already wrote (pcdm_gemm_params.gn_stats_out: per 192-row tile and image slot
-// {sum, sum of squares} of every group): the workgroup first merges the partials of ITS image -- thread (group, sub) Chan-merges every 8th
-// tile's {n, mean, M2 = q - s^2 / n}, the 8 subs are merged through LDS in a fixed order (deterministic) -- while its rows' loads are in
-// flight, then normalises in the access pattern of layernorm_rows_kernel.  One streaming pass: the statistics half of the GroupNorm
-// launch (read all -> exchange -> write all) is gone.
-template <int LPR, int OPL, int ITERS>
-__global__ __launch_bounds__(kThreads) void gn_from_stats_kernel(const u16* __restrict__ x, u16* __restrict__ y, int rows, int HW, int gs,
-                                                               const float* __restrict__ gp /* [tiles][2][G][2] */, int part_rows, float eps,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int fuse_silu) {
-    constexpr int RPW = 64 / LPR, C = 8 * LPR * OPL, RPB = (kThreads / 64) * RPW * ITERS;   // rows per workgroup (HW % RPB == 0: one image)
-    __shared__ float red[kThreads * 3];
-    __shared__ float stat[2 * 256];
-    const int t = threadIdx.x, lane = t & 63, sub = lane % LPR;
-    const int row0 = blockIdx.x * RPB;
-    const int G = C / gs;
-    u16x8 u[ITERS][OPL];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = row0 + (it * (kThreads / 64) + (t >> 6)) * RPW + lane / LPR;
-        const int64_t base = (int64_t)(row < rows ? row : rows - 1) * C;
-#pragma unroll
-        for (int j = 0; j < OPL; ++j) u[it][j] = *(const u16x8*)(x + base + (j * LPR + sub) * 8);
-    }
-    {   // ---- this image's statistics from the producer's partials
-        const int b = row0 / HW;
-        const int64_t i0 = (int64_t)b * HW, i1 = i0 + HW;          // rows of the image
-        const int t_lo = (int)(i0 / part_rows), t_hi = (int)((i1 - 1) / part_rows);
-        const int nsub = kThreads / G > 0 ? kThreads / G : 1;
-        const int sb = t / G, g = t - sb * G;
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        if (sb < nsub) {
-            for (int tt = t_lo + sb; tt <= t_hi; tt += nsub) {
-                const int64_t r_lo = (int64_t)tt * part_rows, r_hi = r_lo + part_rows;
-                const int64_t o_lo = r_lo > i0 ? r_lo : i0, o_hi = r_hi < i1 ? r_hi : i1;
-                const float nj = (float)(o_hi - o_lo) * (float)gs;
-                const int slot = b - (int)(r_lo / HW);
-                const f32x2 sq = *(const f32x2*)(gp + (((int64_t)tt * 2 + slot) * G + g) * 2);
-                const float mj = sq[0] / nj;
-                gn_chan_merge(n, mean, m2, nj, mj, sq[1] - sq[0] * mj);
-            }
-        }
-        red[3 * t] = n;
-        red[3 * t + 1] = mean;
-        red[3 * t + 2] = m2;
-        __syncthreads();
-        if (t < G) {
-            n = mean = m2 = 0.f;
-            for (int j = 0; j < nsub; ++j) gn_chan_merge(n, mean, m2, red[3 * (j * G + t)], red[3 * (j * G + t) + 1], red[3 * (j * G + t) + 2]);
-            float var = n > 0.f ? m2 / n : 0.f;
-            var = var > 0.f ? var : 0.f;
-            stat[2 * t] = mean;
-            stat[2 * t + 1] = 1.0f / sqrtf(var + eps);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < OPL; ++j) {
-        const int c = (j * LPR + sub) * 8;
-        // an octet spans at most two groups (gs >= 8): one division per octet, 16-byte loads of the affine
-        const int g0 = c / gs, brk = (g0 + 1) * gs - c;          // channels e >= brk belong to group g0 + 1
-        const f32x2 s0 = *(const f32x2*)(stat + 2 * g0), s1 = *(const f32x2*)(stat + 2 * (g0 + 1 < G ? g0 + 1 : g0));
-        const f32x4 ga = *(const f32x4*)(gamma + c), gb = *(const f32x4*)(gamma + c + 4), ba = *(const f32x4*)(beta + c), bb = *(const f32x4*)(beta + c + 4);
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float mean_e = e < brk ? s0[0] : s1[0], rstd_e = e < brk ? s0[1] : s1[1];
-            sc[e] = rstd_e * (e < 4 ? ga[e & 3] : gb[e & 3]);
-            sh[e] = (e < 4 ? ba[e & 3] : bb[e & 3]) - mean_e * sc[e];
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int row = row0 + (it * (kThreads / 64) + (t >> 6)) * RPW + lane / LPR;
-            if (row >= rows) continue;
-            u16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf2f(u[it][j][e]) * sc[e] + sh[e];
-                if (fuse_silu) f = f * fast_rcp(1.0f + fast_exp2(-1.44269504088896341f * f));
-                o[e] = f2bf(f);
-            }
-            *(u16x8*)(y + (int64_t)row * C + c) = o;
-        }
-    }
-}
-
-extern "C" int pcdm_groupnorm_from_stats(const void* x, int C, int B, int HW, int groups, float eps, const float* gamma, const float* beta, int fuse_silu,
-                                         void* y, const float* gn_stats, int part_rows, pcdm_stream_t s) {
-    if (!x || !y || !gn_stats || !gamma || !beta || B <= 0 || HW <= 0 || groups <= 0 || groups > 256 || (C != 320 && C != 640) || C % groups ||
-        part_rows <= 0 || part_rows > HW)
-        return -1;
-    const int rows = B * HW;
-    hipStream_t st = (hipStream_t)s;
-#define PCDM_GNFS(LPR_, IT_)                                                                                                              \
-    do {                                                                                                                                  \
-        constexpr int rpb = (kThreads / 64) * (64 / LPR_) * IT_;                                                                          \
-        if (HW % rpb) return -1;                                                                                                          \
-        PCDM_LAUNCH(PCDM_KERNEL_NAME(gn_from_stats_kernel<LPR_, 5, IT_>), dim3(rows / rpb), dim3(kThreads), 0, st, (const u16*)x, (u16*)y, rows, HW,     \
-                    C / groups, gn_stats, part_rows, eps, gamma, beta, fuse_silu);                                                        \
-    } while (0)
-    if (C == 320) PCDM_GNFS(8, 2);     // 64 rows per workgroup (704 workgroups at 8 x 5632 rows)
-    else PCDM_GNFS(16, 4);             // 64 rows per workgroup
-#undef PCDM_GNFS
-    PCDM_CHECK_LAUNCH();
-    return 0;
 }
 
 extern "C" int pcdm_layernorm(const void* x, void* y, int rows, int C, float eps, const float* gamma,

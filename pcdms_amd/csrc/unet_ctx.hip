@@ -183,17 +183,15 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles, or the tiled kernel with in-kernel statistics / producer partials)
         float ln_eps = 0.f;
         int dup_rows = 0;   // pcdm_gemm_params.dup_rows
-        const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride
+        const int32_t* rowvec_step = nullptr;   // pcdm_gemm_params.rowvec_step / rowvec_step_stride / rowvec_step_count / step_error
         int64_t rowvec_step_stride = 0;
+        int rowvec_step_count = 0;
+        int32_t* step_error = nullptr;
         int defer = 0;   // split-K only: 1 = leave the reduce to the GroupNorm that reads `out` next (and let it write `out`), 2 = ... not write it
-        float* gn_stats = nullptr;    // producer: also write the GroupNorm partials of the stored rows (pcdm_gemm_params.gn_stats_out) when the
-        int gn_gs = 0;                //           configuration in use can (full-row tile, no split-K, ...); gn_gs = channels per group
         float* row_stats = nullptr;   // producer: write the LayerNorm partials of the stored rows here when the tile in use can (pcdm_gemm_params.row_stats_out);
                                       // consumer (gemm_ln): the partials of the A rows (used when stats_valid and the table asks for mode 2)
     };
     bool stats_valid = false;   // did the last gemm() that was handed G::row_stats write them?
-    const void* gn_stats_of = nullptr;   // the tensor the GroupNorm partials in "gns" describe (NULL: none), and their group size
-    int gn_stats_gs = 0;
     // the split-K GEMM whose reduce is still pending (pcdm_gemm_params.defer_reduce): consumed by the next groupnorm() on its `out`
     pcdm_gn_splitk_src pend;
     const void* pend_out = nullptr;
@@ -202,6 +200,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         if (rc || !w) return;
         pcdm_gemm_params p;
         memset(&p, 0, sizeof(p));
+        p.struct_size = (uint32_t)sizeof(p);
         p.a = a;
         p.lda = lda;
         p.c1 = g.a2 ? (int)lda : w->K;
@@ -231,6 +230,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.dup_rows = g.dup_rows;
         p.rowvec_step = g.rowvec ? g.rowvec_step : nullptr;
         p.rowvec_step_stride = g.rowvec_step_stride;
+        p.rowvec_step_count = g.rowvec_step_count;
+        p.step_error = g.step_error;
         const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : (g.dup_rows ? 2 : 0)};
         auto it = u->tiles.find(key);
         if (it != u->tiles.end()) {
@@ -242,20 +243,13 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
                 if ((int64_t)p.split_k * M * w->Npad > kSplitKFloats) { p.split_k = 0; p.tile = 0; p.ws = nullptr; p.ws_floats = 0; }
             }
         }
-        if (g.gn_stats) {    // (pcdms_amd.ops.gemm(gn_stats=): the same condition)
-            const int rpb = p.rows_per_batch;
-            const char* gn_env = getenv("PCDM_GN_PRODUCER_STATS");   // (opt-in: measured break-even, profiles/r5_bench_gn_apply.txt)
-            const bool ok = gn_env && gn_env[0] == '1' && p.tile == 21 && p.split_k <= 1 && g.epilogue == PCDM_EPI_STORE && !g.dup_rows && !g.zero_rows &&
-                            !g.row_stats && g.gn_gs >= 8 && 80 % g.gn_gs == 0 && w->N % g.gn_gs == 0 && w->Npad % 320 == 0 && M % 32 == 0 && rpb % 32 == 0 &&
-                            M % rpb == 0 && rpb >= 192 && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0);
-            gn_stats_of = nullptr;
-            if (ok) { p.gn_stats_out = g.gn_stats; p.gn_stats_gs = g.gn_gs; gn_stats_of = out; gn_stats_gs = g.gn_gs; }
-        }
         if (g.row_stats) {   // (pcdms_amd.ops.gemm(row_stats=): the same condition, so that both schedules launch the same instances)
             const int tl = p.tile;
             stats_valid = (tl == 2 || tl == 4 || tl == 5 || tl == 6 || tl == 7 || tl == 8 || tl == 10 || tl == 18) && p.split_k <= 1 && !g.conv &&
                           g.epilogue == PCDM_EPI_STORE && w->N % 32 == 0;
             if (stats_valid) p.row_stats_out = g.row_stats;
+        } else {
+            stats_valid = false;   // (a launch that was not asked for partials invalidates the ones an earlier launch left: ADVICE r5)
         }
         if (pend_out) { rc = -1; u->err = "a deferred split-K reduce was never consumed"; return; }
         if (g.defer && p.split_k > 1 && g.epilogue == PCDM_EPI_STORE && p.ldo == w->N && (!g.residual || g.res_mod == M || g.res_mod == 0) &&
@@ -265,6 +259,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
             pend.part = p.ws; pend.split_k = p.split_k; pend.M = M; pend.N = w->N; pend.Npad = w->Npad;
             pend.bias = p.bias; pend.rowvec = p.rowvec; pend.ldrv = g.rowvec ? (g.ldrv ? g.ldrv : w->N) : 0;
             pend.rowvec_step = p.rowvec_step; pend.rowvec_step_stride = p.rowvec_step_stride;
+            pend.rowvec_step_count = p.rowvec_step_count; pend.step_error = p.step_error;
             pend.residual = p.residual; pend.ldr = p.ldr;
             pend.pre_out = out; pend.store_pre = g.defer == 1;
             pend_out = out;
@@ -286,6 +281,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
             if (it != u->tiles.end() && it->second.first > 0) {   // (0 = LayerNorm launch + plain GEMM; 31.. rowgemm.hip; else an LNF instance of gemm.hip)
                 pcdm_gemm_params p;
                 memset(&p, 0, sizeof(p));
+        p.struct_size = (uint32_t)sizeof(p);
                 p.a = a; p.lda = lda; p.c1 = w->K;
                 p.w = w_ln->w; p.M = M; p.N = w_ln->N; p.K = w_ln->K; p.Npad = w_ln->Npad;
                 p.bias = w_ln->bias;
@@ -304,16 +300,11 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
             }
         }
         chk(pcdm_layernorm(a, ln_buf, M, w->K, eps, gamma, beta, st), "pcdm_layernorm");
+        g.row_stats = nullptr;   // (here it meant the CONSUMER's partials; gemm() would read it as a producer request -- pcdms_amd.ops' two_launches() passes none)
         gemm(ln_buf, w->K, M, w, out, g);
     }
-    void groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, float eps, const float* gamma, const float* beta, int silu, void* y,
-                   const float* gn_stats = nullptr) {
+    void groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, float eps, const float* gamma, const float* beta, int silu, void* y) {
         if (rc) return;
-        const int G_ = u->cfg.norm_groups;
-        if (gn_stats && !pend_out && !x2 && gn_stats_of == x1 && (C1 == 320 || C1 == 640) && HW % 64 == 0 && C1 % G_ == 0 && gn_stats_gs == C1 / G_) {
-            chk(pcdm_groupnorm_from_stats(x1, C1, B, HW, G_, eps, gamma, beta, silu, y, gn_stats, 192, st), "pcdm_groupnorm_from_stats");
-            return;   // (the producer left the group sums: normalise only -- pcdms_amd.ops.groupnorm(gn_stats=))
-        }
         if (pend_out) {
             if (pend_out != x1 || pend.N != C1) { rc = -1; u->err = "deferred split-K reduce: the next GroupNorm reads another tensor"; return; }
             pend_out = nullptr;
@@ -404,7 +395,7 @@ int make_plan(pcdm_unet* u, int B, int h, int w, int L) {
         }
     }
     for (const char* nm : {"r", "rb", "u", "ub", "r2", "c1", "sc", "t0", "t1", "ln", "q2", "at", "us"}) P.add(nm, act);
-    P.add("gns", ((int64_t)B * h * w / 192 + 2) * 2 * 256 * 2 * 4);   // GroupNorm partials: [tiles of 192 rows][2][groups <= 256][2] fp32
+    P.add("step_err", kAlign);       // int32: a forward found the device step counter outside the time table (pcdm_unet_step_overflow)
     P.add("rs", act / 8 + kAlign);   // LayerNorm partials: [M][C / 32][2] fp32 = an eighth of an activation's bytes
     P.add("gn", act_gn);
     P.add("ff", act_ff);
@@ -631,6 +622,7 @@ extern "C" int pcdm_unet_prepare_timesteps(pcdm_unet* u, const int64_t* t_dev, i
     {   // the SAME tile as the per-step launch (M = B rows): identical bits
         pcdm_gemm_params p;
         memset(&p, 0, sizeof(p));
+        p.struct_size = (uint32_t)sizeof(p);
         p.a = emb_bf; p.lda = D; p.c1 = tp->K;
         p.w = tp->w; p.M = n * B; p.N = tp->N; p.K = tp->K; p.Npad = tp->Npad;
         p.bias = tp->bias;
@@ -645,6 +637,30 @@ extern "C" int pcdm_unet_prepare_timesteps(pcdm_unet* u, const int64_t* t_dev, i
     it->second.time_table = tab;
     it->second.time_steps = n;
     it->second.time_t_dev = t_dev;
+#ifdef PCDM_EMU
+    *R.buf<int32_t>("step_err") = 0;
+#else
+    if (hipMemsetAsync(R.buf<int32_t>("step_err"), 0, sizeof(int32_t), (hipStream_t)s) != hipSuccess) return -1000;
+#endif
+    return 0;
+}
+
+// Has a forward on this workspace read the time table with a device step counter outside [0, n)?  (the consumers clamp it and raise this flag:
+// pcdm_gemm_params.rowvec_step_count / step_error).  Synchronous 4-byte read behind everything enqueued on s.
+extern "C" int pcdm_unet_step_overflow(pcdm_unet* u, void* workspace, int* flag_out, pcdm_stream_t s) {
+    if (!u || !workspace || !flag_out) return -1;
+    const auto cit = u->cond_of_ws.find(workspace);
+    if (cit == u->cond_of_ws.end()) { u->err = "pcdm_unet_prepare_conditioning has not run on this workspace"; return -1; }
+    if (make_plan(u, cit->second.B, cit->second.h, cit->second.w, cit->second.L)) return -1;
+    Run R{u, (char*)workspace, s};
+    int32_t v = 0;
+#ifdef PCDM_EMU
+    v = *R.buf<int32_t>("step_err");
+#else
+    if (hipMemcpyAsync(&v, R.buf<int32_t>("step_err"), sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess) return -1000;
+    if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return -1000;
+#endif
+    *flag_out = v != 0;
     return 0;
 }
 
@@ -673,6 +689,8 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     const bool use_table = cit->second.time_table && step_dev && cit->second.time_t_dev == t_dev;
     const int32_t* rv_step = use_table ? step_dev : nullptr;
     const int64_t rv_stride = use_table ? (int64_t)B * temb_n : 0;
+    const int rv_count = use_table ? cit->second.time_steps : 0;          // the step counter is bounded into the table on the device (ABI 4)
+    int32_t* rv_err = use_table ? R.buf<int32_t>("step_err") : nullptr;
     if (!use_table) {
         R.chk(pcdm_timestep_embedding(t_dev, step_dev, R.buf<float>("t_emb"), B, C0, c.flip_sin_to_cos, c.freq_shift, s), "pcdm_timestep_embedding");
         const PW *t1 = R.pw("time_embedding.linear_1"), *t2 = R.pw("time_embedding.linear_2");
@@ -701,8 +719,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = hh; g.Wo = ww;
         g.rowvec = temb + toff.at(p); g.ldrv = temb_n; g.rows_per_batch = HW_;
         g.rowvec_step = rv_step; g.rowvec_step_stride = rv_stride;
-        float* gns = R.buf<float>("gns");   // GroupNorm partials of the tensor in flight (round 5; pcdms_amd/unet.py::resnet)
-        g.gn_stats = gns; g.gn_gs = cout / G;
+        g.rowvec_step_count = rv_count; g.step_error = rv_err;
         if (shared_in) {   // the CFG halves still have the same x1: norm1 and conv1's contraction once, two epilogues
             const int Bs = B / 2, Ms = Bs * HW_;
             chk_gn_half(x1, C1, Bs, HW_, eps, R.vec(p + "norm1.weight"), R.vec(p + "norm1.bias"));
@@ -713,7 +730,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             g.defer = 2;
             R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
         }
-        R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"), gns);
+        R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
         const void* res = x1;
         if (u->w.count(p + "conv_shortcut")) {
             Run::G gs;
@@ -724,7 +741,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         Run::G g2;
         g2.conv = 1; g2.B = B; g2.Hi = hh; g2.Wi = ww; g2.Ho = hh; g2.Wo = ww;
         g2.residual = res; g2.ldr = cout; g2.res_mod = M;
-        g2.rows_per_batch = HW_; g2.gn_stats = gns; g2.gn_gs = cout / G;
+        g2.rows_per_batch = HW_;
         g2.defer = gn_next ? 1 : 0;
         void* out = R.buf(out_name);
         R.gemm(R.buf("gn"), cout, M, cv2, out, g2);
@@ -734,13 +751,10 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     auto transformer = [&](const std::string& p, const void* x, int cc, int H, int HW_, const std::string& out_name) -> void* {
         const int M = B * HW_;
         const std::string b = p + "transformer_blocks.0.";
-        R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"), R.buf<float>("gns"));
+        R.groupnorm(x, cc, nullptr, 0, B, HW_, 1e-6f, R.vec(p + "norm.weight"), R.vec(p + "norm.bias"), 0, R.buf("gn"));
         const int64_t r0 = (int64_t)n0 * HW_;
         float* rs = R.buf<float>("rs");            // LayerNorm partials of the rows in flight: [M][cc / 32][2] (round 5; pcdms_amd/unet.py::transformer)
         auto twin = [&](const char* nm) -> const PW* { return u->w.count(p + nm) ? &u->w[p + nm] : nullptr; };
-        // (opt-in, PCDM_XATTN_QPROJ=1: measured slower than the launches it replaces, profiles/r5_bench_xattn.txt)
-        const char* xq_env = getenv("PCDM_XATTN_QPROJ");
-        const bool xq = xq_env && xq_env[0] == '1' && !u->attn_fp8 && twin("q2_ln") && twin("q2_ln")->wsum;
         Run::G g0;
         if (R.ln_wants_stats(M, R.pw(p + "qkv"), twin("qkv_ln"), PCDM_EPI_SPLIT_VT)) g0.row_stats = rs;
         R.gemm(R.buf("gn"), cc, M, R.pw(p + "proj_in"), R.buf("t0"), g0);
@@ -764,24 +778,19 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         {
             Run::G g;
             g.residual = R.buf("t0"); g.ldr = cc; g.res_mod = M;
-            if (!xq && R.ln_wants_stats(M - (int)r0, R.pw(p + "q2"), twin("q2_ln"), PCDM_EPI_STORE)) g.row_stats = rs;
+            if (R.ln_wants_stats(M - (int)r0, R.pw(p + "q2"), twin("q2_ln"), PCDM_EPI_STORE)) g.row_stats = rs;
             R.gemm(R.buf("at"), cc, M, R.pw(p + "o1"), R.buf("t1"), g);
         }
         // cross-attention over the context tokens; the first n0 batch entries have an all-zero context: attn2(x) == to_out.0.bias there
         u16 *t1 = R.buf<u16>("t1"), *ln = R.buf<u16>("ln"), *q2 = R.buf<u16>("q2"), *at = R.buf<u16>("at");
-        if (xq) {   // LayerNorm2 -> to_q inside the attention kernel (pcdms_amd/unet.py::transformer, ops.flash_attn_qproj)
-            const PW* wl = twin("q2_ln");
-            R.chk(pcdm_flash_attn_qproj(t1 + r0 * cc, cc, cc, wl->w, wl->bias, wl->wsum, 1e-5f, R.buf("k2:" + p), cc, R.buf("vt2:" + p), lp8(L), at + r0 * cc, cc,
-                                        B - n0, H, HW_, L, 0.125f, s), "pcdm_flash_attn_qproj");
-        } else {
+        {
             Run::G g;
             g.row_stats = rs + r0 * (cc / 32) * 2;
             const PW* wl = u->w.count(p + "q2_ln") ? &u->w[p + "q2_ln"] : nullptr;
             R.gemm_ln(t1 + r0 * cc, cc, M - (int)r0, R.pw(p + "q2"), wl, R.vec(b + "norm2.weight"), R.vec(b + "norm2.bias"), 1e-5f, ln + r0 * cc, q2 + r0 * cc, g);
         }
         if (R.rc) return nullptr;
-        if (xq) {
-        } else if (u->attn_fp8)
+        if (u->attn_fp8)
             R.chk(pcdm_flash_attn_fp8(q2 + r0 * cc, cc, R.buf("k2_8:" + p), cc, R.buf("vt2_8:" + p), lp16(L), at + r0 * cc, cc, B - n0, H, HW_, L, 0.125f, 1.0f,
                                       1.0f, 5.0f, s), "pcdm_flash_attn_fp8");
         else

@@ -69,7 +69,7 @@ class DeferredGemm:
     ``groupnorm`` takes this object as its first source (``pcdm_groupnorm_splitk``): it reduces while it loads, and writes ``out`` iff
     ``store`` (something else -- a residual, a skip -- reads the tensor later).  Nothing else may touch the split-K workspace in between."""
 
-    __slots__ = ("part", "split_k", "M", "N", "Npad", "bias", "rowvec", "ldrv", "rowvec_step", "rowvec_step_stride", "rpb", "residual", "ldr", "out",
+    __slots__ = ("part", "split_k", "M", "N", "Npad", "bias", "rowvec", "ldrv", "rowvec_step", "rowvec_step_stride", "rowvec_step_count", "step_error", "rpb", "residual", "ldr", "out",
                  "store", "keep")
 
     def __init__(self, **kw):
@@ -90,22 +90,9 @@ def as_tensor(x: Union[torch.Tensor, "DeferredGemm"]) -> torch.Tensor:
     return x.tensor() if isinstance(x, DeferredGemm) else x
 
 
-GN_PRODUCER_STATS = os.environ.get("PCDM_GN_PRODUCER_STATS", "0") == "1"   # opt-in (round 5): GroupNorm statistics written by the producing GEMM -- measured
-#                                                                             break-even (profiles/r5_bench_gn_apply.txt: convolution +3..5 us, GroupNorm 22.0 -> 15.6 us, end to end +0.07 %)
-GN_PART_ROWS = 192                                                          # rows per partial = BM of the producer tile (21)
-_GN_STATS_OF: dict = {}                                                     # stats storage -> (data_ptr of the tensor they describe, group size)
-
-
-def gn_stats_for(gn_stats: Optional[torch.Tensor], x: torch.Tensor, gs: int) -> bool:
-    """do the partials in ``gn_stats`` describe exactly the tensor ``x`` at group size ``gs`` (written by the ``gemm(..., gn_stats=)`` that produced it)?"""
-    return gn_stats is not None and torch.is_tensor(x) and _GN_STATS_OF.get(gn_stats.untyped_storage().data_ptr()) == (x.data_ptr(), gs)
-
-
 def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor], B: int, HW: int, groups: int, eps: float,
-              gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor,
-              gn_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16.  x1 may be a ``DeferredGemm``.  ``gn_stats``: the group sums
-    the producer of x1 left (``gemm(..., gn_stats=)``); when they describe x1 the launch only normalises (pcdm_groupnorm_from_stats)."""
+              gamma: torch.Tensor, beta: torch.Tensor, silu: bool, out: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
+    """x1 [B*HW, C1] (+ optional x2 [B*HW, C2]) bf16 -> out [B*HW, C1+C2] bf16.  x1 may be a ``DeferredGemm``."""
     C1 = x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
     _c(out, BF16); _c(gamma, torch.float32); _c(beta, torch.float32)
@@ -114,17 +101,14 @@ def groupnorm(x1: Union[torch.Tensor, "DeferredGemm"], x2: Optional[torch.Tensor
     if log:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if x2 is None and C1 in (320, 640) and HW % 64 == 0 and C1 % groups == 0 and gn_stats_for(gn_stats, x1, C1 // groups):
-        _c(x1, BF16)
-        _chk(_lib.lib().pcdm_groupnorm_from_stats(_ptr(x1), C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta), int(silu), _ptr(out), _ptr(gn_stats),
-                                                 GN_PART_ROWS, _stream(x1)), "pcdm_groupnorm_from_stats")
-    elif isinstance(x1, DeferredGemm):
+    if isinstance(x1, DeferredGemm):
         d = x1
         assert d.M == B * HW and d.N == C1 and (d.rowvec is None or d.rpb == HW), "rowvec rows must be the GroupNorm's batch entries"
         sp = _lib.GnSplitKSrc()
         sp.part, sp.split_k, sp.M, sp.N, sp.Npad = d.part, d.split_k, d.M, d.N, d.Npad
         sp.bias, sp.rowvec, sp.ldrv, sp.residual, sp.ldr = d.bias, d.rowvec, d.ldrv, d.residual, d.ldr
         sp.rowvec_step, sp.rowvec_step_stride = d.rowvec_step, d.rowvec_step_stride
+        sp.rowvec_step_count, sp.step_error = d.rowvec_step_count, d.step_error
         sp.pre_out, sp.store_pre = _ptr(_c(d.out, BF16)), int(d.store)
         rc = _lib.lib().pcdm_groupnorm_splitk(C.byref(sp), _ptr(x2), C2, B, HW, groups, eps, _ptr(gamma), _ptr(beta), int(silu),
                                              _ptr(out), _ptr(ws), _stream(out))
@@ -252,8 +236,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          use_bias: bool = True, split_k: int = 1, w_ld: int = 0, act: int = ACT_NONE, zero_rows: int = 0,
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
          defer_reduce: Optional[bool] = None, dup_rows: int = 0, rowvec_step: Optional[torch.Tensor] = None,
-         rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None, gn_stats: Optional[torch.Tensor] = None,
-         gn_gs: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
+         rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None, rowvec_step_count: int = 0,
+         step_error: Optional[torch.Tensor] = None) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
 
@@ -269,7 +253,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     result is that GroupNorm and that no other split-K GEMM runs in between.  ``None``: never defer.
 
     ``rowvec_step`` (device int32 counter) / ``rowvec_step_stride`` (floats): the row-vector block in use is ``rowvec + *rowvec_step *
-    rowvec_step_stride`` -- the per-step slice of a table that holds the time-embedding projections of every denoise step.
+    rowvec_step_stride`` -- the per-step slice of a table that holds the time-embedding projections of every denoise step.  ``rowvec_step_count``
+    (> 0: the blocks behind ``rowvec``) bounds the counter ON THE DEVICE: a value outside ``[0, count)`` is clamped into the table and ``step_error``
+    (device int32) set to 1 -- the launch never reads beyond the table (pcdm_gemm_params.rowvec_step_count, ABI 4).
 
     ``dup_rows`` (conv only): ``out`` has ``M + dup_rows`` rows; rows ``m + dup_rows`` get the same contraction with THEIR row-vector /
     residual rows (``pcdm_gemm_params.dup_rows``: the CFG-shared prefix of the UNet)."""
@@ -310,6 +296,10 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         if rowvec_step is not None:
             assert rowvec_step.dtype == torch.int32 and rowvec_step.device == rowvec.device
             p.rowvec_step, p.rowvec_step_stride = _ptr(rowvec_step), int(rowvec_step_stride)
+            p.rowvec_step_count = int(rowvec_step_count)
+            if step_error is not None:
+                assert step_error.dtype == torch.int32 and step_error.device == rowvec.device
+                p.step_error = _ptr(step_error)
     if residual is not None:
         _c(residual, BF16)
         p.residual = _ptr(residual)
@@ -337,19 +327,6 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     elif split_k > 1:
         split = split_k
     p.tile = tile
-    if gn_stats is not None:
-        # producer of GroupNorm partials (pcdm_gemm_params.gn_stats_out: [ceil(M / 192)][2][N / gn_gs][2] fp32): the full-row tile's STORE epilogue
-        # only; any other configuration leaves the buffer alone and the GroupNorm that follows takes its own statistics
-        rpb_ = rows_per_batch or M
-        ok = GN_PRODUCER_STATS and tile == 21 and split == 1 and epilogue == EPI_STORE and act == ACT_NONE and not dup_rows and not zero_rows and \
-            row_stats is None and gn_gs >= 8 and 80 % gn_gs == 0 and pw.N % gn_gs == 0 and pw.Npad % 320 == 0 and M % 32 == 0 and rpb_ % 32 == 0 and \
-            M % rpb_ == 0 and rpb_ >= 192 and out.dim() == 2 and out.is_contiguous() and (residual is None or res_mod in (0, M))
-        if ok:
-            assert gn_stats.dtype == torch.float32 and gn_stats.is_contiguous() and gn_stats.numel() >= ((M + 191) // 192) * 2 * (pw.N // gn_gs) * 2
-            p.gn_stats_out, p.gn_stats_gs = _ptr(gn_stats), gn_gs
-            _GN_STATS_OF[gn_stats.untyped_storage().data_ptr()] = (out.data_ptr(), gn_gs)
-        else:
-            _GN_STATS_OF.pop(gn_stats.untyped_storage().data_ptr(), None)
     if row_stats is not None:
         # producer of LayerNorm partials (pcdm_gemm_params.row_stats_out): [M][N / 32][2] fp32, written by the STORE epilogue of the tiles that
         # have such an instance; any other configuration leaves the buffer alone and says so (the consumer then takes its own statistics)
@@ -367,8 +344,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
             p.defer_reduce = 1
             deferred = DeferredGemm(part=ws.data_ptr(), split_k=split, M=M, N=pw.N, Npad=pw.Npad, bias=p.bias, rowvec=p.rowvec,
                                     ldrv=p.ldrv if rowvec is not None else 0, rowvec_step=p.rowvec_step, rowvec_step_stride=p.rowvec_step_stride,
+                                    rowvec_step_count=p.rowvec_step_count, step_error=p.step_error,
                                     rpb=p.rows_per_batch, residual=p.residual, ldr=p.ldr, out=out,
-                                    store=bool(defer_reduce), keep=(ws, rowvec, residual, pw, rowvec_step))
+                                    store=bool(defer_reduce), keep=(ws, rowvec, residual, pw, rowvec_step, step_error))
     if LAUNCH_LOG is not None and a.is_cuda:  # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -657,33 +635,6 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Te
     if log:
         e1.record()
         LAUNCH_LOG.append(("flash_attn_kernel", 4.0 * B * H * Lq * Lk * 64, e0, e1, (B, H, Lq, Lk)))
-    return out
-
-
-XATTN_QPROJ = os.environ.get("PCDM_XATTN_QPROJ", "0") == "1"   # opt-in (measured slower than the two launches it replaces: profiles/r5_bench_xattn.txt)
-
-
-def flash_attn_qproj(x: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Lq: int,
-                     Lk: int, ln_eps: float = 1e-5, scale: Optional[float] = None) -> torch.Tensor:
-    """Cross-attention with ``LayerNorm -> to_q`` inside the attention kernel (pcdm_flash_attn_qproj): ``x`` [B*Lq, C] token rows, ``pw_q`` the
-    to_q weight packed by ``pack_linear_ln`` (LayerNorm folded; ``wsum`` None = plain projection, no LayerNorm).  The projection's FLOPs are
-    logged with the attention launch (same algorithmic total as the two launches it replaces)."""
-    for t in (x, k, vt, out):
-        assert t.dtype == BF16
-    C_ = pw_q.K
-    assert x.stride(1) == 1 and x.shape[1] == C_ and pw_q.N == H * 64 and k.stride(1) == 1 and vt.is_contiguous() and out.stride(1) == 1
-    scale = scale if scale is not None else 1.0 / math.sqrt(64)
-    log = LAUNCH_LOG is not None and x.is_cuda
-    if log:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    rc = _lib.lib().pcdm_flash_attn_qproj(_ptr(x), x.stride(0), C_, _ptr(pw_q.w), _ptr(pw_q.bias) if pw_q.bias is not None else None,
-                                         _ptr(_c(pw_q.wsum, torch.float32)) if pw_q.wsum is not None else None, float(ln_eps),
-                                         _ptr(k), k.stride(0), _ptr(vt), vt.shape[-1], _ptr(out), out.stride(0), B, H, Lq, Lk, scale, _stream(x))
-    _chk(rc, "pcdm_flash_attn_qproj")
-    if log:
-        e1.record()
-        LAUNCH_LOG.append(("flash_attn_kernel", 4.0 * B * H * Lq * Lk * 64 + 2.0 * B * Lq * C_ * (H * 64), e0, e1, (B, H, Lq, Lk, "qproj")))
     return out
 
 

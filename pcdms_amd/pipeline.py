@@ -412,7 +412,13 @@ class Stage2_InpaintDiffusionPipeline:
                 self._step_eager(st)
                 if callback is not None and i % callback_steps == 0:
                     callback(i, timesteps[i], st["lat"])
-        return st["lat"].clone()
+        out = st["lat"].clone()
+        # the device step counter indexes the per-call time table inside the kernels: they bound it (a counter beyond the table is clamped,
+        # never an out-of-bounds read) and raise a flag -- read once per sampling call (one 4-byte copy behind the loop)
+        if hasattr(unet, "step_overflow") and unet.step_overflow():
+            raise RuntimeError("the device step counter left the time-embedding table of this sampling call (clamped on the device): "
+                               "the schedule ran more steps than prepare_conditioning(timesteps=...) was given")
+        return out
 
 
 class Simple_Stage2_InpaintDiffusionPipeline(Stage2_InpaintDiffusionPipeline):

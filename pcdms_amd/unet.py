@@ -99,7 +99,7 @@ def _as_tuple(v, n):
 class Conditioning:
     """Step-invariant part of one sampling call (``prepare_conditioning``): views of the model's scratch buffers."""
 
-    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv", "shared_halves", "temb_all", "temb_steps")
+    __slots__ = ("gen", "B", "h", "w", "L", "n0", "cls_emb", "pose_nhwc", "kv", "shared_halves", "temb_all", "temb_steps", "step_error")
 
     def __init__(self, gen: int, B: int, h: int, w: int, L: int):
         self.gen, self.B, self.h, self.w, self.L = gen, B, h, w, L
@@ -107,6 +107,7 @@ class Conditioning:
         self.shared_halves = False       # batch entries b and b + B/2 have the same sample / mask / masked latents / pose (the CFG halves)
         self.temb_all: Optional[torch.Tensor] = None   # fp32 [steps, B, sum Cout]: every resnet's time_emb_proj(silu(emb)) for EVERY step
         self.temb_steps: Optional[torch.Tensor] = None  # the timestep table it was computed for
+        self.step_error: Optional[torch.Tensor] = None  # device int32: a forward found the step counter outside that table (clamped on the device)
         self.cls_emb: Optional[torch.Tensor] = None
         self.pose_nhwc: Optional[torch.Tensor] = None
         self.kv: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -500,6 +501,14 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         ops.gemm(emb_bf, W["temb"], out, rows_per_batch=1, epilogue=ops.EPI_NCHW_F32, tile=tile if split <= 1 else 8)
         cond.temb_all = out.view(n, B, W["temb_n"])
         cond.temb_steps = ts
+        cond.step_error = self._buf("step_err", (4,), torch.int32, zero=True)[:1]
+        cond.step_error.zero_()
+
+    def step_overflow(self) -> bool:
+        """Did a forward since the last ``prepare_conditioning(timesteps=...)`` read the per-call time table with a device step counter outside ``[0, n)``?  The kernels
+        clamp such a counter into the table (no out-of-bounds read) and raise this flag (pcdm_gemm_params.rowvec_step_count / step_error).
+        Synchronises."""
+        return bool(int(self._buf("step_err", (4,), torch.int32, zero=True)[0].item()) != 0)
 
     def _conditioning_for(self, B, h, w, ehs, class_labels, pose, zero_ctx_batches: Optional[int] = None) -> "Conditioning":
         """Bare ``forward`` callers (the reference pipeline's own loop): reuse the last conditioning
@@ -595,13 +604,13 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         else:
             t_dev = torch.tensor([int(timestep)], dtype=torch.int64, device=dev)
         cls_emb, pose_nhwc, kv, L, nzero = cond.cls_emb, cond.pose_nhwc, cond.kv, cond.L, cond.n0
-        rv_step, rv_stride = None, 0
+        rv_step, rv_stride, rv_count, rv_err = None, 0, 0, None
         if cond.temb_all is not None and step_dev is not None and torch.is_tensor(timestep) and timestep.data_ptr() == cond.temb_steps.data_ptr() \
                 and timestep.numel() == cond.temb_steps.numel():
             # the time-embedding projections of every step were computed with the conditioning (prepare_conditioning(timesteps=...)): this
             # step's block is picked inside the kernels by the device step counter -- nothing to launch here
             temb = cond.temb_all[0]
-            rv_step, rv_stride = step_dev, cond.temb_all.stride(0)
+            rv_step, rv_stride, rv_count, rv_err = step_dev, cond.temb_all.stride(0), cond.temb_all.shape[0], cond.step_error
         else:
             t_emb = ops.timestep_embedding(t_dev, step_dev, self._buf("t_emb", (B, boc[0]), torch.float32),
                                            cfg.flip_sin_to_cos, float(cfg.freq_shift))
@@ -624,35 +633,32 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             cin, cout, M = r["cin"], r["cout"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
             tv = temb[:, r["toff"]: r["toff"] + cout]
-            # round 5: the convolutions also leave the GROUP sums of the rows they store (ops.gemm(gn_stats=): the full-row tile of level 0), so that
-            # the GroupNorm reading the tensor next -- norm2 after conv1, Transformer2DModel.norm after conv2 -- only normalises
-            gns = self._buf("gns", ((M + 191) // 192, 2, G, 2), torch.float32)
             if shared:   # the CFG halves still have the same x1 here: norm1 and conv1's contraction once, two epilogues (temb rows b / b + B/2)
                 Bs, Ms = B // 2, (B // 2) * HW_
                 n1 = ops.groupnorm(x1[:Ms], None, Bs, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin))[:Ms], ws)
                 h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=dict(B=Bs, Hi=hh, Wi=ww, Ho=hh, Wo=ww), rowvec=tv,
-                              rows_per_batch=HW_, dup_rows=Ms, rowvec_step=rv_step, rowvec_step_stride=rv_stride)
+                              rows_per_batch=HW_, dup_rows=Ms, rowvec_step=rv_step, rowvec_step_stride=rv_stride, rowvec_step_count=rv_count,
+                              step_error=rv_err)
                 cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
             else:
                 n1 = ops.groupnorm(x1, x2, B, HW_, G, eps, r["n1"][0], r["n1"][1], True, self._buf("gn", (M, cin)), ws)
                 x1 = ops.as_tensor(x1)   # (written by the norm above if it was deferred)
                 cv = dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww)
                 h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False,
-                              rowvec_step=rv_step, rowvec_step_stride=rv_stride, gn_stats=gns, gn_gs=cout // G)
-            n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws, gn_stats=gns)
+                              rowvec_step=rv_step, rowvec_step_stride=rv_stride, rowvec_step_count=rv_count, step_error=rv_err)
+            n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
             else:
                 res = x1
             return ops.gemm(n2, r["conv2"], self._buf(name, (M, cout)), conv=cv, residual=res, res_mod=M,
-                            defer_reduce=True if gn_next else None, rows_per_batch=HW_, gn_stats=gns, gn_gs=cout // G)
+                            defer_reduce=True if gn_next else None, rows_per_batch=HW_)
 
         def transformer(p, x, HW_, name):
             a = W[p]
             c, H, M = a["c"], a["heads"], B * HW_
             ws = self._buf("gnws", (int(ops._lib.lib().pcdm_groupnorm_ws_floats(B, 4096)),), torch.float32, zero=True)
-            n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws,
-                               gn_stats=self._buf("gns", ((M + 191) // 192, 2, G, 2), torch.float32))
+            n0 = ops.groupnorm(x, None, B, HW_, G, 1e-6, a["norm"][0], a["norm"][1], False, self._buf("gn", (M, c)), ws)
             x = ops.as_tensor(x)
             # Row statistics travel with the rows (round 5, levels 1-3): the linear that writes the input of a LayerNorm -- proj_in, attn1.to_out +
             # residual, attn2.to_out + residual -- also writes the {sum, M2} of every 32-column run (`row_stats`), and the LayerNorm-folded
@@ -675,21 +681,15 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 at = ops.flash_attn_fp8(qk[:, :c], k8, vt8.view(B, c, HW16), self._buf("at", (M, c)), B, H, HW_, HW_)
             else:
                 at = ops.flash_attn(qk[:, :c], qk[:, c:], vt, self._buf("at", (M, c)), B, H, HW_, HW_)
-            # round 5: LayerNorm2 -> to_q runs INSIDE the cross-attention kernel (ops.flash_attn_qproj: one launch instead of two or three)
-            xq = ops.XATTN_QPROJ and not self._attn_fp8 and a.get("q2_ln") is not None
-            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M,
-                          row_stats=None if xq else want(a.get("q2_ln"), M - r0, ops.EPI_STORE))
+            t1 = ops.gemm(at, a["o1"], self._buf("t1", (M, c)), residual=t0, res_mod=M, row_stats=want(a.get("q2_ln"), M - r0, ops.EPI_STORE))
             # cross-attention over the context tokens; the first n0 batch entries have an all-zero context, for which
             # attn2(x) == to_out.0.bias exactly: their rows skip LN2 / to_q / attention and enter
             # the to_out GEMM as zero A rows (no main loop for tiles that lie entirely inside them)
             k2, vt2 = kv[p]
             at2 = self._buf("at", (M, c))
-            if xq:
-                ops.flash_attn_qproj(t1[r0:], a["q2_ln"], k2, vt2, at2[r0:], B - nzero, H, HW_, L, ln_eps=1e-5)
-            else:
-                q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
-                              ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"), row_stats=None if rs is None else rs[r0:])
-                (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
+            q2 = ops.gemm(t1[r0:], a["q2"], self._buf("q2", (M, c))[r0:], ln=(a["ln2"][0], a["ln2"][1], 1e-5),
+                          ln_buf=self._buf("ln", (M, c))[r0:], pw_ln=a.get("q2_ln"), row_stats=None if rs is None else rs[r0:])
+            (ops.flash_attn_fp8 if self._attn_fp8 else ops.flash_attn)(q2, k2, vt2, at2[r0:], B - nzero, H, HW_, L)
             t2 = ops.gemm(at2, a["o2"], self._buf("t0", (M, c)), residual=t1, res_mod=M, zero_rows=r0,
                           row_stats=want(a.get("ff1_ln"), M, ops.EPI_GEGLU))
             # GEGLU feed-forward

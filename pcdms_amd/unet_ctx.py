@@ -164,6 +164,15 @@ class UNetContext:
         self._chk(_lib.lib().pcdm_unet_prepare_timesteps(self._h, t_dev.data_ptr(), n, tab.data_ptr(), ws.data_ptr(), ops._stream(ws)),
                   "pcdm_unet_prepare_timesteps")
 
+    def step_overflow(self, B: int, h: int, w: int) -> bool:
+        """``pcdm_unet_step_overflow``: did a forward on this shape's workspace find the device step counter outside the prepared time table?
+        (clamped on the device, never an out-of-bounds read).  Synchronises."""
+        import ctypes as C
+        ws = self.workspace(B, h, w, self._L)
+        flag = C.c_int(0)
+        self._chk(_lib.lib().pcdm_unet_step_overflow(self._h, ws.data_ptr(), C.byref(flag), ops._stream(ws)), "pcdm_unet_step_overflow")
+        return bool(flag.value)
+
     @torch.no_grad()
     def forward(self, x_in: torch.Tensor, t_dev: torch.Tensor, step_dev: Optional[torch.Tensor], B: int, h: int, w: int, pose_b: int,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -5,7 +5,7 @@ would pass them.  Every such test therefore calls ``check(n
 
 * ``value <= tol`` -- the stated tolerance (the contract);
 * ``value <= SLACK * recorded + FLOOR`` where ``recorded`` is the value the same test measured on the MI355X when
-  ``profiles/r5_parity_values.json`` was committed -- the regression guard (different boxes and tuner choices move these numbers
+  ``profiles/r6_parity_values.json`` was committed -- the regression guard (different boxes and tuner choices move these numbers
   by a few per cent; ``SLACK`` = 1.25);
 * the measured value is appended to ``gpurun_out/parity_values.json`` (the GPU box's scratch directory, merged back by gpurun), from
   which the committed record is refreshed: ``python tests/parity_record.py gpurun_out/parity_values.json`` rewrites the profile.
@@ -18,7 +18,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-RECORD = ROOT / "profiles" / "r5_parity_values.json"   # (starts as a copy of the round-4 record; refreshed values are listed old -> new)
+RECORD = ROOT / "profiles" / "r6_parity_values.json"   # (starts as a copy of the round-5 record; refreshed values are listed old -> new)
 OUT = ROOT / "gpurun_out" / "parity_values.json"
 SLACK, FLOOR = 1.25, 1e-6
 
@@ -43,7 +43,7 @@ def check(name: str, value: float, tol: float) -> None:
     rec = _load(RECORD).get("values", {}).get(name)
     if rec is not None and os.environ.get("PCDM_PARITY_NO_RECORD") != "1":
         assert value <= SLACK * float(rec) + FLOOR, \
-            f"{name}: {value:.4g} is more than {SLACK}x the recorded measurement {float(rec):.4g} (profiles/r5_parity_values.json)"
+            f"{name}: {value:.4g} is more than {SLACK}x the recorded measurement {float(rec):.4g} (profiles/r6_parity_values.json)"
 
 
 if __name__ == "__main__":   # refresh the committed record from a GPU run's output
@@ -57,12 +57,12 @@ if __name__ == "__main__":   # refresh the committed record from a GPU run's out
     RECORD.write_text(json.dumps({"note": "rel-L2 / pixel-level values measured by the -m gpu tests on MI355X; tests assert <= 1.25x these "
                                           "(tests/parity_record.py)", "values": merged}, indent=1, sort_keys=True) + "\n")
     print(f"{RECORD}: {len(merged)} values ({len(vals)} refreshed)")
-    # old -> new of every refreshed value, for the commit message / profiles/r5_parity_delta.txt (a refresh must show
+    # old -> new of every refreshed value, for the commit message / profiles/r6_parity_delta.txt (a refresh must show
     # what it moved)
     lines = []
     for k in sorted(vals):
         o = old.get("values", {}).get(k)
         lines.append(f"{k:48s} {'new' if o is None else format(float(o), '.4g'):>10s} -> {float(vals[k]):.4g}" +
                      ("" if o is None or not float(o) else f"  ({float(vals[k]) / float(o):.3f}x)"))
-    (ROOT / "profiles" / "r5_parity_delta.txt").write_text("\n".join(lines) + "\n")
+    (ROOT / "profiles" / "r6_parity_delta.txt").write_text("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -52,7 +52,7 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_struct_layouts_match_the_header(tmp_path):
     """The ctypes mirrors in pcdms_amd/_lib.py against the C structs of include/pcdm.h as gcc lays them out: size and the offset of every
     field (pcdm_gemm_params grew without a version bump -- an ABI drift between the header and a binding must fail a test, and
-    ``pcdm_version()`` must say 3 for the struct that ends with ``row_stats_out``)."""
+    ``pcdm_version()`` must say 4 for the struct that starts with ``struct_size`` and ends with ``step_error``)."""
     import shutil
     import subprocess
 
@@ -82,4 +82,36 @@ def test_struct_layouts_match_the_header(tmp_path):
     body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct pcdm_gemm_params {"):hdr.index("} pcdm_gemm_params;")], flags=re.S)
     names = re.findall(r"(\w+)\s*(?:,|;)", body.split("{", 1)[1])
     assert names == [f for f, _ in _lib.GemmParams._fields_], (names, [f for f, _ in _lib.GemmParams._fields_])
-    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 3
+    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 4
+
+
+def test_gemm_params_of_another_size_are_refused(monkeypatch):
+    """ABI 4: ``pcdm_gemm_params.struct_size`` is the first field; a host compiled against an older (shorter) or newer header is refused with -1
+    before any other field is read (version agreement used to be advisory).  On the emulator build: the SAME call succeeds with
+    the right size and is refused with any other; on the product library (no GPU here) the refusal precedes every launch."""
+    import torch
+
+    from pcdms_amd import _lib, ops
+    from pcdms_amd.build import build_lib
+    from tests.emu import build_emu
+    assert _lib.GemmParams.struct_size.offset == 0 and _lib.GemmParams().struct_size == ctypes.sizeof(_lib.GemmParams)
+    _lib.use_library(build_emu.load())
+    a = torch.randn(64, 64).to(torch.bfloat16)
+    pw = ops.pack_linear(torch.randn(64, 64), None, torch.device("cpu"))
+    out = torch.empty(64, 64, dtype=torch.bfloat16)
+    ops.gemm(a, pw, out, tile=2)                                             # well-formed: runs
+    real_init = _lib.GemmParams.__init__
+    for bad in (0, ctypes.sizeof(_lib.GemmParams) - 16, ctypes.sizeof(_lib.GemmParams) + 8, 0x7f000000):
+        def init(self, *args, _bad=bad, **kw):
+            real_init(self, *args, **kw)
+            self.struct_size = _bad
+        monkeypatch.setattr(_lib.GemmParams, "__init__", init)
+        with pytest.raises(RuntimeError, match="code -1"):
+            ops.gemm(a, pw, out, tile=2)
+    monkeypatch.setattr(_lib.GemmParams, "__init__", real_init)
+    ops.gemm(a, pw, out, tile=2)
+    lib = ctypes.CDLL(str(build_lib()))
+    lib.pcdm_gemm.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    p = _lib.GemmParams()
+    p.struct_size = ctypes.sizeof(_lib.GemmParams) - 16                      # (the version-3 struct was 16 bytes shorter)
+    assert lib.pcdm_gemm(ctypes.byref(p), None) == -1

@@ -98,3 +98,50 @@ def test_hip_reproduces_reference_pipeline(gpu_backend, kind):
                num_images_per_prompt=int(z["N"]), guidance_scale=2.0, num_inference_steps=int(z["steps"]),
                guidance_rescale=float(z["guidance_rescale"]) if "guidance_rescale" in z else 0.0, output_type="latent").latents
     assert _rel(out, _t(z, "final_latents")) < 5e-2, _rel(out, _t(z, "final_latents"))
+
+
+def test_reference_precision_budget_fixture_and_emulation_hook():
+    """tests/golden/fp16_budget.npz (make_fp16_budget.py: the reference's own fp16 numerics against the fp32 oracle) is self-consistent, its fp32
+    leg IS the committed configs[0] oracle run, and ``oracle.unet.ROUND_DTYPE`` is a no-op unless set: ``None`` reproduces the plain fp32 forward
+    bit for bit, fp16 / bf16 change it by their rounding (tiny configuration, CPU)."""
+    import json
+
+    import oracle.unet as OU
+    bx = np.load(G / "fp16_budget.npz")
+    budget = json.loads(str(bx["json"]))
+    c0 = np.load(G / "fullsize_config0.npz")
+    assert np.abs(bx["config0_final_fp32"] - c0["lat_final"]).max() <= 1e-5 * np.abs(c0["lat_final"]).max()
+    for i in ("0", "10", "25"):
+        b = budget["forward_configs1"][i]
+        assert 5e-4 < b["fp16ref_vs_fp32"] < 5e-3 < b["bf16ref_vs_fp32"] < 4e-2 and b["fp32_vs_stored_fixture"] < 1e-3   # (the stored eps are fp16)
+        assert 4 < b["bf16ref_vs_fp32"] / b["fp16ref_vs_fp32"] < 12                     # 3 mantissa bits
+    f16, b16 = budget["config0"]["fp16"], budget["config0"]["bf16"]
+    assert f16["final_latents"] < b16["final_latents"] and f16["per_step_latents"][0] < f16["per_step_latents"][-1]
+    ref = torch.from_numpy(bx["config0_final_fp32"])
+    for key, r in (("config0_final_fp16", f16["final_latents"]), ("config0_final_bf16", b16["final_latents"])):
+        got = ((torch.from_numpy(bx[key]) - ref).norm() / ref.norm()).item()
+        assert abs(got - r) <= 1e-3 * r
+    # the hook
+    cfg = UNetConfig.tiny()
+    sd = synth_state_dict(cfg, seed=3, random_affine=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 9, 16, 16, generator=g)
+    ehs = torch.randn(2, 5, cfg.cross_attention_dim, generator=g)
+    cl = torch.randn(2, 1, cfg.projection_class_embeddings_input_dim, generator=g)
+    pose = torch.randn(2, cfg.block_out_channels[0], 16, 16, generator=g) * 0.1
+    assert OU.ROUND_DTYPE is None
+    with torch.no_grad():
+        base = unet_forward(sd, cfg, x, 500, ehs, cl, pose)
+        outs = {}
+        for dt in (torch.float16, torch.bfloat16):
+            OU.ROUND_DTYPE = dt
+            try:
+                sdq = {k: v.to(dt).float() for k, v in sd.items()}
+                outs[dt] = unet_forward(sdq, cfg, x.to(dt).float(), 500, ehs.to(dt).float(), cl.to(dt).float(), pose.to(dt).float())
+            finally:
+                OU.ROUND_DTYPE = None
+        again = unet_forward(sd, cfg, x, 500, ehs, cl, pose)
+    assert torch.equal(base, again)
+    r16 = ((outs[torch.float16] - base).norm() / base.norm()).item()
+    rbf = ((outs[torch.bfloat16] - base).norm() / base.norm()).item()
+    assert 1e-4 < r16 < 3e-3 < rbf < 1e-1 and 4 < rbf / r16 < 12 and torch.equal(outs[torch.float16], outs[torch.float16].half().float())

@@ -505,52 +505,6 @@ def test_flash_attn_strided_output(backend):
         ops.flash_attn(qd, kd, vtd, odd[:, :Cc], B, H, Lq, Lk)
 
 
-@pytest.mark.parametrize("case", ["level0", "level1", "level2", "plain"])
-def test_flash_attn_qproj(backend, case):
-    """Cross-attention with ``LayerNorm -> to_q`` inside the attention kernel (round 5, pcdm_flash_attn_qproj): against the composition it
-    replaces computed in fp64 / fp32 -- LayerNorm(x) W_q^T rounded to bf16, then softmax attention over the 258 context tokens -- and
-    against the library's own unfused path (folded-LayerNorm GEMM -> pcdm_flash_attn).  Ragged query counts, rows with a large common
-    offset (the shifted row sums), the three channel widths of the UNet; ``plain``: no LayerNorm (wsum = NULL)."""
-    dev = backend.device
-    if backend.is_emu:
-        B, H, Lq, Lk = {"level0": (1, 1, 40, 66), "level1": (2, 2, 33, 70), "level2": (1, 3, 24, 20), "plain": (1, 2, 70, 66)}[case]
-    else:
-        B, H, Lq, Lk = {"level0": (4, 5, 5632, 258), "level1": (4, 10, 1408, 258), "level2": (4, 20, 352 - 5, 258), "plain": (2, 10, 1000, 258)}[case]
-    C = H * 64
-    g = torch.Generator().manual_seed(470)
-    x = torch.randn(B * Lq, C, generator=g) * (torch.rand(B * Lq, 1, generator=g) * 2 + 0.3)
-    if case == "plain":
-        x = x * 0.4        # (no LayerNorm in front: keep the scores in the range LayerNorm'ed rows give -- a near-one-hot softmax turns a
-    else:                  #  bf16 flip of q into an O(1) output change, which is not what this test is about)
-        x[::5] += 10.0     # rows whose |mean| >> std
-    x = x.to(BF16)
-    wq = rnd(C, C, seed=471, scale=1 / math.sqrt(C))
-    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
-    k, v = rnd(B * Lk, C, seed=472), rnd(B * Lk, C, seed=473)
-    Lp = (Lk + 7) // 8 * 8
-    vt = torch.zeros(B, C, Lp, dtype=BF16)
-    vt[:, :, :Lk] = v.view(B, Lk, C).permute(0, 2, 1)
-    if case == "plain":
-        pw_q = ops.pack_linear(wq.float(), None, dev)
-        qref = (x.double() @ wq.double().t()).to(BF16)
-    else:
-        pw_q = ops.pack_linear_ln(wq.float(), None, gamma, beta, dev)
-        qref = (F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5) @ wq.double().t()).to(BF16)
-    out = torch.full((B * Lq, C), float("nan"), dtype=BF16, device=dev)
-    ops.flash_attn_qproj(x.to(dev), pw_q, k.to(dev), vt.to(dev), out, B, H, Lq, Lk)
-    backend.sync()
-    ref = _attn_ref(qref, k, v, B, H, Lq, Lk)
-    close(out, ref, tol=1.5e-2)
-    if case != "plain":   # the unfused path of the library on the same operands
-        q2 = torch.empty(B * Lq, C, dtype=BF16, device=dev)
-        ops.gemm(x.to(dev), ops.pack_linear(wq.float(), None, dev), q2, ln=(gamma.to(dev), beta.to(dev), 1e-5),
-                 ln_buf=torch.empty(B * Lq, C, dtype=BF16, device=dev), pw_ln=None)
-        o2 = torch.empty_like(out)
-        ops.flash_attn(q2, k.to(dev), vt.to(dev), o2, B, H, Lq, Lk)
-        backend.sync()
-        close(out, o2.float(), tol=1.5e-2)
-
-
 def _e4m3(x: torch.Tensor) -> torch.Tensor:
     """OCP e4m3fn round trip (RNE, saturating) -- torch's own float8_e4m3fn cast, used only as the test's quantiser."""
     return x.float().clamp(-448, 448).to(torch.float8_e4m3fn).float()
@@ -777,6 +731,51 @@ def test_gemm_full_row_tiles_and_zero_rows(backend):
         ops.gemm(xh, pwc, out, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tile=tile)
         backend.sync()
         close(out.view(B, H, W, Cout), refc)
+
+
+def test_rowvec_step_counter_is_bounded_on_the_device(backend):
+    """ABI 4: the device step counter that selects the per-step block of a row-vector table (the time-embedding projections of every
+    denoise step) is BOUNDED inside the kernels: a value beyond the table is clamped to its last block (negative: to the first) and a device
+    flag raised -- the launch never reads foreign memory.  The plain epilogue, the split-K reduce kernel and the GroupNorm that consumes
+    deferred split-K slabs all take the counter; an in-range counter leaves the flag alone."""
+    dev = backend.device
+    M, K, N, nblk = (96, 128, 64, 3) if backend.is_emu else (2816, 2560, 1280, 5)
+    B = 2
+    rpb = M // B
+    a = rnd(M, K, seed=500)
+    pw = ops.pack_linear(rnd(N, K, seed=501, scale=1 / math.sqrt(K)).float(), None, dev)
+    table = torch.randn(nblk, B, N, generator=torch.Generator().manual_seed(502))
+    tab_dev = torch.cat([table.reshape(-1), torch.full((4 * B * N,), float("nan"))]).to(dev)   # NaN behind the table: an unclamped read would show
+    base = a.float() @ pw.w[:N].float().cpu().t()
+    for step_v, want_blk, want_flag in ((1, 1, 0), (nblk - 1, nblk - 1, 0), (nblk, nblk - 1, 1), (nblk + 3, nblk - 1, 1), (-2, 0, 1)):
+        for sk in (1, 2):
+            step = torch.tensor([step_v], dtype=torch.int32, device=dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            ops.gemm(a.to(dev), pw, out, rowvec=tab_dev[: B * N].view(B, N), rows_per_batch=rpb, rowvec_step=step, rowvec_step_stride=B * N,
+                     rowvec_step_count=nblk, step_error=err, tile=2, split_k=sk)
+            backend.sync()
+            close(out, base + table[want_blk].repeat_interleave(rpb, 0))
+            assert int(err.item()) == want_flag, (step_v, sk)
+    # the deferred split-K reduce inside the GroupNorm
+    G = 8
+    gamma, beta = torch.rand(N, generator=torch.Generator().manual_seed(503)) + 0.5, torch.zeros(N)
+    ws = ops.groupnorm_ws(B, N, dev)
+    for step_v, want_blk, want_flag in ((0, 0, 0), (nblk + 1, nblk - 1, 1)):
+        step = torch.tensor([step_v], dtype=torch.int32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        pre = torch.empty(M, N, dtype=BF16, device=dev)
+        d = ops.gemm(a.to(dev), pw, pre, rowvec=tab_dev[: B * N].view(B, N), rows_per_batch=rpb, rowvec_step=step, rowvec_step_stride=B * N,
+                     rowvec_step_count=nblk, step_error=err, tile=2, split_k=2, defer_reduce=True)
+        assert isinstance(d, ops.DeferredGemm)
+        y = torch.empty(M, N, dtype=BF16, device=dev)
+        ops.groupnorm(d, None, B, rpb, G, 1e-5, gamma.to(dev), beta.to(dev), False, y, ws)
+        backend.sync()
+        x = (base + table[want_blk].repeat_interleave(rpb, 0)).to(BF16).float()
+        ref = F.group_norm(x.view(B, rpb, N).permute(0, 2, 1), G, gamma, beta, 1e-5).permute(0, 2, 1).reshape(M, N)
+        close(y, ref, tol=2e-2)
+        close(pre, x)
+        assert int(err.item()) == want_flag, step_v
 
 
 def test_gemm_uneven_176_row_tiles(backend):
@@ -1148,81 +1147,6 @@ def test_gemm_row_stats_producer_and_consumer(backend):
     st2 = torch.zeros(M, C // 32, 2, dtype=torch.float32, device=dev)
     ops.gemm(x.to(dev), pw0, t, tile=21 if pw0.Npad % 320 == 0 else 1, row_stats=st2) if pw0.Npad % 128 == 0 else None
     assert not ops.row_stats_valid(st2)
-
-
-@pytest.mark.parametrize("kind", ["conv_rowvec", "conv_residual", "linear_residual"])
-def test_groupnorm_producer_statistics(backend, kind, monkeypatch):
-    """Round 5: the GEMM that writes a tensor also leaves its GroupNorm group sums (``gemm(..., gn_stats=)``: tile 21, per 192-row tile and
-    image slot), and ``groupnorm(..., gn_stats=)`` then only normalises (pcdm_groupnorm_from_stats).  192-row tiles that straddle two
-    images, time-embedding rows / residuals in the producing epilogue, channel offsets of 20 standard deviations: the partials against
-    sums taken from the stored tensor, the normalised output against ``F.group_norm`` (fp64) and against the library's own
-    single-launch GroupNorm on the same tensor."""
-    dev = backend.device
-    monkeypatch.setattr(ops, "GN_PRODUCER_STATS", True)      # (opt-in in the product: PCDM_GN_PRODUCER_STATS=1; undone by the fixture, also on failure)
-    g = torch.Generator().manual_seed(490)
-    B, H, W, C, G = (2, 8, 32, 320, 32) if backend.is_emu else (8, 64, 88, 320, 32)
-    HW, M, gs = H * W, B * H * W, C // G
-    cin = 64 if backend.is_emu else 320
-    gamma, beta = (torch.rand(C, generator=g) + 0.5), torch.randn(C, generator=g) * 0.5
-    stats = torch.full(((M + 191) // 192, 2, G, 2), float("nan"), dtype=torch.float32, device=dev)
-    out = torch.full((M, C), float("nan"), dtype=BF16, device=dev)
-    chan_off = (torch.randn(C, generator=g) * 20.0)                         # per-channel offsets >> the spread (bias of the producer)
-    if kind.startswith("conv"):
-        x = rnd(B, H, W, cin, seed=491)
-        w = rnd(C, cin, 3, 3, seed=492, scale=1 / math.sqrt(9 * cin))
-        pw = ops.pack_conv3x3(w.float(), chan_off, dev)
-        kw = dict(conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), rows_per_batch=HW)
-        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), chan_off, padding=1).permute(0, 2, 3, 1).reshape(M, C)
-        if kind == "conv_rowvec":
-            tv = torch.randn(B, C, generator=g)
-            kw["rowvec"] = tv.to(dev)
-            ref = ref + tv.repeat_interleave(HW, 0)
-        else:
-            res = rnd(M, C, seed=493)
-            kw.update(residual=res.to(dev), res_mod=M)
-            ref = ref + res.float()
-        a = x.to(dev)
-    else:
-        a0 = rnd(M, cin, seed=494)
-        w = rnd(C, cin, seed=495, scale=1 / math.sqrt(cin))
-        pw = ops.pack_linear(w.float(), chan_off, dev)
-        res = rnd(M, C, seed=496)
-        kw = dict(residual=res.to(dev), res_mod=M, rows_per_batch=HW)
-        ref = a0.float() @ w.float().t() + chan_off + res.float()
-        a = a0.to(dev)
-    ops.gemm(a, pw, out, tile=21, gn_stats=stats, gn_gs=gs, **kw)
-    backend.sync()
-    assert ops.gn_stats_for(stats, out, gs)
-    close(out, ref)
-    # the partials against the stored tensor
-    o = out.float().cpu().view(M, G, gs)
-    got = stats.cpu()
-    for t in range((M + 191) // 192):
-        r0, r1 = t * 192, min(M, (t + 1) * 192)
-        b0 = r0 // HW
-        for slot in (0, 1):
-            lo, hi = max(r0, (b0 + slot) * HW), min(r1, (b0 + slot + 1) * HW)
-            if lo >= hi:
-                continue
-            blk = o[lo:hi]
-            want_s, want_q = blk.sum((0, 2)), (blk * blk).sum((0, 2))
-            assert (got[t, slot, :, 0] - want_s).abs().max() <= 1e-3 * want_s.abs().max() + 1e-2, (t, slot)
-            # (the partials are taken from the fp32 values in front of the bf16 rounding -- the 192 x 320 tile has no registers to spare for the
-            #  rounded copies --, the reference sums from the stored bf16 tensor: 2^-9 relative per element, a few 1e-3 on a sum of squares whose
-            #  terms share the sign of a large channel offset)
-            assert (got[t, slot, :, 1] - want_q).abs().max() <= 4e-3 * want_q.abs().max() + 1e-2, (t, slot)
-    # the normalise-only GroupNorm against the fp64 reference and the library's own single launch
-    ref_n = F.silu(F.group_norm(out.double().cpu().view(B, HW, C).permute(0, 2, 1), G, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1).reshape(M, C)
-    ws = ops.groupnorm_ws(B, C, dev)
-    y1, y2 = torch.full((M, C), float("nan"), dtype=BF16, device=dev), torch.empty(M, C, dtype=BF16, device=dev)
-    ops.groupnorm(out, None, B, HW, G, 1e-5, gamma.to(dev), beta.to(dev), True, y1, ws, gn_stats=stats)
-    ops.groupnorm(out, None, B, HW, G, 1e-5, gamma.to(dev), beta.to(dev), True, y2, ws)
-    backend.sync()
-    close(y1, ref_n, tol=6e-3)
-    close(y1, y2.float(), tol=6e-3)
-    # partials that describe ANOTHER tensor are not used
-    other = out.clone()
-    assert not ops.gn_stats_for(stats, other, gs)
 
 
 def _all_bf16_in(lo: float, hi: float, stride: int = 1) -> torch.Tensor:

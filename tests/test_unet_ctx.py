@@ -375,3 +375,50 @@ def test_c_context_starts_with_the_committed_tuning_table():
     assert all(v > 0 for v in seen.values()), seen
     assert lib.pcdm_unet_get_tile(h, 0, 12345, 64, 64, 0, 0, 0, 0, 0, 0, 0, None, None) == -1
     lib.pcdm_unet_destroy(h)
+
+
+def test_step_counter_beyond_the_time_table_is_clamped_and_reported(backend):
+    """ADVICE r4 #1 / VERDICT r5 next #7: ``pcdm_unet_forward`` picks the time-embedding block of a step by a DEVICE counter; a counter beyond the
+    table of ``pcdm_unet_prepare_timesteps`` used to read out of bounds (documented, not enforced).  ABI 4: every consumer clamps the counter
+    into the table on the device and raises a flag -- ``pcdm_unet_step_overflow`` (C schedule) / ``unet.step_overflow()`` (Python schedule).
+    In range: flag 0 and the output of the step; out of range: the LAST step's output (bit for bit), flag 1, no fault."""
+    dev = backend.device
+    cfg = UNetConfig.tiny()
+    B, h, w, L, n0 = (2, 8, 8, 5, 1) if backend.is_emu else (4, 16, 24, 9, 2)
+    sd = synth_state_dict(cfg, seed=3, random_affine=True)
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(sd)
+    m.to(dev)
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(B, cfg.in_channels, h, w, generator=g)
+    e = torch.randn(B, L, cfg.cross_attention_dim, generator=g)
+    e[:n0] = 0
+    c = torch.randn(B, 1, cfg.projection_class_embeddings_input_dim, generator=g) * 0.4
+    p = torch.randn(1, cfg.block_out_channels[0], h, w, generator=g) * 0.1
+    ts = torch.tensor([801, 401, 1], dtype=torch.int64, device=dev)
+    # ---- Python schedule
+    cond = m.prepare_conditioning(B, h, w, e.to(dev), c.to(dev), p.to(dev), zero_ctx_batches=n0, timesteps=ts)
+    x_in = ops.nchw_to_nhwc_bf16(s.to(dev), cpad=m._w["conv_in"].cin)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    outs = {}
+    for sv in (0, 2, 7):
+        step.fill_(sv)
+        outs[sv] = m._forward_nhwc(x_in, B, h, w, ts, cond, step_dev=step).clone()
+        backend.sync()
+        assert m.step_overflow() == (sv >= 3), sv
+    assert not torch.equal(outs[0], outs[2]) and torch.equal(outs[7], outs[2])
+    m.prepare_conditioning(B, h, w, e.to(dev), c.to(dev), p.to(dev), zero_ctx_batches=n0, timesteps=ts)   # a new table clears the flag
+    assert not m.step_overflow()
+    # ---- C schedule
+    ctx = UNetContext(m)
+    pose_b = ctx.prepare_conditioning(B, h, w, e, c, p, zero_ctx_batches=n0)
+    ctx.prepare_timesteps(ts, B, h, w)
+    couts = {}
+    for sv in (2, 5):
+        step.fill_(sv)
+        couts[sv] = ctx.forward(x_in, ts, step, B, h, w, pose_b).clone()
+        backend.sync()
+        assert ctx.step_overflow(B, h, w) == (sv >= 3), sv
+    assert torch.equal(couts[2], outs[2]) and torch.equal(couts[5], outs[2])
+    ctx.prepare_timesteps(ts, B, h, w)
+    assert not ctx.step_overflow(B, h, w)
