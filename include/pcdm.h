@@ -125,7 +125,7 @@ typedef struct pcdm_gemm_params {
     int32_t zero_rows; /* linear only: the caller guarantees A rows [0, zero_rows) are all-zero; they are not read and tiles entirely
                           inside them run the epilogue only.  The CFG unconditional half of attn2.to_out: context == 0 => attention
                           output == 0 => out = bias + residual (stage2_inpaint_pipeline.py:457-458) */
-    const float* ln_wsum;  /* non-NULL (tiles 31..36: the A-in-registers kernel, K = 320; tiles 2 / 4 / 7 / 8 / 17 / 18 / 26: the folded instances of the tiled
+    const float* ln_wsum;  /* non-NULL (tiles 31..36: the A-in-registers kernel, K = 320; tiles 2 / 4 / 7 / 8 / 17 / 18 / 23 / 26: the folded instances of the tiled
                               kernel, any K, see ln_row_stats): W and bias carry a FOLDED LayerNorm -- W' = W diag(gamma),
                               bias' = bias + W beta (BasicTransformerBlock.norm1/2/3 in front of to_q|k|v, to_q and the GEGLU projection: K8 fused into
                               K7 / K11) -- and ln_wsum[n] = sum_k W'[n, k] (fp32 [Npad], of the bf16 values).  The kernel takes each A row's mean / rstd
@@ -146,7 +146,7 @@ typedef struct pcdm_gemm_params {
                               but its own time embedding -- the two classifier-free-guidance halves at conv_in and at the first ResnetBlock2D's
                               conv1 (stage2_inpaint_pipeline.py:499-501 doubles the latents; mask, masked latents and pose are shared).  Needs
                               N % 8 == 0, ldo % 8 == 0, rows_per_batch >= 32 and dup_rows % rows_per_batch == 0 with a rowvec; else -1 */
-    const float* ln_row_stats;  /* with ln_wsum on a tiled instance (tiles 2 / 4 / 7 / 8 / 17 / 18 / 26): [M][K / 32][2] fp32 -- per A row and 32-column run
+    const float* ln_row_stats;  /* with ln_wsum on a tiled instance (tiles 2 / 4 / 7 / 8 / 17 / 18 / 26; 23 with partials only): [M][K / 32][2] fp32 -- per A row and 32-column run
                                    {sum, sum of squares about the run's own mean}, as left by the launch that produced A with row_stats_out -- the
                                    kernel merges them into the row's LayerNorm statistics (Chan) instead of taking them in its K loop (NULL: in the
                                    loop, every N tile again: pays for N <~ 1280 only).  K % 64 == 0, K <= 1280, 16-byte aligned */

@@ -463,6 +463,7 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
                                    void* o, int64_t ldo, int B, int H, int Lq, int Lk, float scale, float thr_log2, pcdm_stream_t s) {
     if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
     if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 8 || ldvt < Lk) return -1;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) != 0) return -1;   // (16-byte row accesses: the base addresses too -- ADVICE r5)
     if (!(thr_log2 >= 0.f) || thr_log2 > 16.f) return -1;
     if ((int64_t)Lk * ldk * 2 >= 0x7fffffffLL || (int64_t)64 * ldvt * 2 >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);

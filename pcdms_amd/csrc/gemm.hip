@@ -76,6 +76,10 @@ int dispatch_tile(int tile, const GemmArgs& a, hipStream_t st) {
         // carries 6 + 5.  Same LDS (the A stage keeps 192 row slots, 16 of them never fetched), same registers, same schedule as 21 / 26.
         case 22: return launch_gemm<176, 320, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves, 128 KiB, 1 block / CU
         case 23: return launch_gemm<176, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96|80 x 64: GEGLU-capable), 112 KiB
+        // (Round 6 also measured 16x16x32-fragment twins of tiles 17 / 1 / 18 / 4 -- ids 24 / 25 / 29 / 30; the instruction is ~9 % more energy-efficient on
+        //  this power-limited part: 4-15 % FASTER per launch back to back on the N = 640 / 1280 / 5120 shapes and 0.15-0.5 % SLOWER end to end in three
+        //  interleaved same-box A/Bs (profiles/r6_tile_f16.txt, r6_ab_tiles.json): removed.  Back-to-back launches of one problem -- weights resident
+        //  in the Infinity Cache, one kernel's steady-state clock -- do not rank tiles the way the denoise step does; as in rounds 3 / 4.)
         // (measured and dropped, never selected by the tuner: 128x320 / 4 waves; 96x320 / 4 waves of 96x80 with two or three stages;
         //  128x160 / 2 waves with three stages)
         case 26: return launch_gemm<192, 256, 2, 4, 2, CONV, false, 16>(a, st);   // 8 waves (96x64 each: GEGLU-capable), 112 KiB

@@ -23,6 +23,7 @@ EPI_STORE, EPI_GEGLU, EPI_SPLIT_VT, EPI_NCHW_F32 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 BF16 = torch.bfloat16
 LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
+LAUNCH_KEYS: Optional[list] = None  # set to [] by tools/tune_in_step.py: (index into LAUNCH_LOG, tuning-table key) of every table-driven GEMM launch
 AUTOTUNE = True                    # pick the GEMM tile configuration per problem shape at first use (GPU only)
 DEFER_SPLITK = os.environ.get("PCDM_DEFER_SPLITK", "1") != "0"   # split-K reduce folded into the consuming GroupNorm (A/B switch)
 
@@ -318,6 +319,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.ldo2 = out2.shape[-1]
     stream = _stream(a)
     split = 1
+    key = None
     if tile == 0 and AUTOTUNE:
         key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
                a2 is not None, residual is not None) + ((True,) if zero_rows else ((2,) if dup_rows else ()))   # (w_ld does not change the best tile)
@@ -356,6 +358,8 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         # field is what the launch executes
         LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split),
                            2.0 * (M - zero_rows) * pw.alg_nk))
+        if LAUNCH_KEYS is not None and key is not None:
+            LAUNCH_KEYS.append((len(LAUNCH_LOG) - 1, key))
         return out if deferred is None else deferred
     _chk(_lib.lib().pcdm_gemm(C.byref(p), stream), "pcdm_gemm")
     return out if deferred is None else deferred
@@ -393,6 +397,8 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
     key = ("ln", M, pw.Npad, pw.K, epilogue)
     have_stats = row_stats_valid(row_stats)
     choice = (tile, mode or (2 if have_stats else 1)) if tile else _TUNED.get(key)   # (an explicit tile: partials are used when there are valid ones)
+    if LAUNCH_KEYS is not None and not tile:
+        LAUNCH_KEYS.append((-1, key))   # (occurrence marker: tools/tune_in_step.py also meets the pairs that run as two launches)
     if not LN_TILED and not tile and pw.K != 320:   # PCDM_LN_TILED=0: A/B switch -- levels 1-3 keep their LayerNorm launches
         pw_ln = None
     stream = _stream(a)
@@ -469,6 +475,8 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
         if log:
             e1.record()
             LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, False, choice, 1), 2.0 * M * pw.alg_nk))
+            if LAUNCH_KEYS is not None and not tile:
+                LAUNCH_KEYS.append((len(LAUNCH_LOG) - 1, key))
         return out
     two_launches()
     return out

@@ -111,3 +111,72 @@ def test_run_sharded_rccl_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True, 2), (1, True, 2)]
+
+
+def _pipe_worker(rank, world, port, q):
+    """run_sharded over the REAL sampler: the stage-2 pipeline on the lane-emulator build of the kernel sources (tiny UNet, one DDIM step)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pipeline import synth_inputs
+    from oracle.unet import UNetConfig, synth_state_dict
+    from pcdms_amd import _lib
+    from pcdms_amd.pipeline import Stage2_InpaintDiffusionPipeline
+    from pcdms_amd.schedulers import DDIMScheduler
+    from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
+    from tests.emu import build_emu
+    from tests.test_schedulers import SD21
+    from tests.test_unet import _kwargs
+    _lib.use_library(build_emu.load())
+    cfg = UNetConfig.tiny()
+    m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+    m.load_state_dict(synth_state_dict(cfg, seed=0, random_affine=True))      # replicated weights: the same seed on every rank
+    pipe = Stage2_InpaintDiffusionPipeline(m, DDIMScheduler.from_config(SD21))
+    N, h, w = 1, 8, 8
+    base = synth_inputs(cfg, h, w, N, L_img=4)
+    calls = {"n": 0}
+
+    def sample(pair):   # one (source, target) pair = its own seeded latents and conditioning
+        calls["n"] += 1
+        g = torch.Generator().manual_seed(100 + int(pair))
+        inp = dict(base, latents=torch.randn(base["latents"].shape, generator=g), s_img_proj_f=torch.randn(base["s_img_proj_f"].shape, generator=g))
+        return pipe(height=h * 8, width=w * 8, num_images_per_prompt=N, guidance_scale=2.0, num_inference_steps=1, output_type="latent",
+                    use_graph=False, **inp).latents
+    sample.example_output = torch.zeros(N, 4, h, w)
+    pairs = [0, 1, 2]                                     # chunks [0] and [1, 2] (the reference's split: remainder into the last chunk)
+    res = run_sharded(pairs, sample)
+    mine = calls["n"]
+    # every rank holds every pair's result, in pair order; check one pair of the OTHER rank's chunk by recomputing it here
+    other = 2 if rank == 0 else 0
+    again = sample(other)
+    ok = len(res) == 3 and mine == (1 if rank == 0 else 2) and torch.equal(res[other], again) and not torch.equal(res[0], res[1]) and \
+        all(torch.isfinite(r).all() for r in res)
+    gathered = [torch.zeros(3, N, 4, h, w) for _ in range(world)]
+    dist.all_gather(gathered, torch.stack(res))           # (test only: both ranks must hold the SAME list)
+    ok = ok and torch.equal(gathered[0], gathered[1])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_sharded_gloo_world2_with_the_real_pipeline_on_the_emulator():
+    """The data-parallel harness around the product's own sampler: two gloo ranks, three pairs split like the reference
+    (/root/reference/stage2_batchtest_inpaint_model.py:25-31,266-285), each pair sampled by ``Stage2_InpaintDiffusionPipeline`` on the lane emulator,
+    one all-gather; every rank ends with all three results in pair order, and a pair computed on the other rank equals a local recomputation."""
+    from tests.emu import build_emu
+    build_emu.build()                                     # (before the ranks start: they must not race on the emulator build)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]

@@ -30,6 +30,11 @@ def key_fields(k):
 def main():
     import json
     write = "--write" in sys.argv
+    cand_tiles = (22, 23)
+    for i, a_ in enumerate(sys.argv):   # --tiles 24,25,29,30: the 16x16x32-fragment twins of the 32x32x16 tiles (same tool, other candidates)
+        if a_ == "--tiles":
+            cand_tiles = tuple(int(x) for x in sys.argv[i + 1].split(","))
+    uneven = set(cand_tiles) <= {22, 23}
     tab_path = ops.TUNING_FILE
     tab = json.loads(Path(tab_path).read_text())
     gem = tab["gemm"]
@@ -41,20 +46,20 @@ def main():
             continue
         f = key_fields(k)
         M, Npad, K = f["M"], f["Npad"], f["K"]
-        if M % 176 or M not in (45056, 22528, 11264, 5632, 2816, 1408, 704) or f["epi"] not in (0, 1):
+        if (uneven and M % 176) or M not in (45056, 22528, 11264, 5632, 2816, 1408, 704) or f["epi"] not in (0, 1):
             continue
         cands = []
-        for t in (22, 23):
-            bn = ops.TILE_SHAPES[t][1]
+        for t in cand_tiles:
+            bm, bn = ops.TILE_SHAPES[t]
             if Npad % bn:
                 continue
-            if f["epi"] == 1 and t != 23:
+            if f["epi"] == 1 and t in (22,):
                 continue
-            ntiles = (M // 176) * (Npad // bn)
+            ntiles = -(-M // bm) * (Npad // bn)
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
                 if sk > 1 and (f["epi"] != 0 or ntiles * sk > 512 or (K // 64) // sk < 4):
                     continue
-                if ntiles * sk < 128:
+                if ntiles * sk < 100:
                     continue
                 cands.append((t, sk))
         if not cands or v[0] in (31, 32, 33, 34, 35, 36):
@@ -133,11 +138,11 @@ def main():
             f = k.split(",")
             if len(f) > 9 and ",".join(f[:9]) in changed:
                 gem[k] = changed[",".join(f[:9])]
-        tab["note"] = (tab.get("note", "") + " | round 6: 176-row tiles (22 / 23) where tools/bench_tile176.py measured them >= 1.5 % faster").strip()
+        tab["note"] = (tab.get("note", "") + f" | round 6: tiles {cand_tiles} where tools/bench_tile176.py measured them >= 1.5 % faster").strip()
         Path(tab_path).write_text(json.dumps(tab, indent=0))
         print(f"wrote {tab_path}")
     Path("gpurun_out").mkdir(exist_ok=True)
-    Path("gpurun_out/r6_tile176_changes.json").write_text(json.dumps(changed, indent=0))
+    Path("gpurun_out/r6_tile_changes_" + "_".join(map(str, cand_tiles)) + ".json").write_text(json.dumps(changed, indent=0))
 
 
 if __name__ == "__main__":

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round 5, the committed measurements in one GPU session: HBM traffic passes on the final kernel sources, the bench line that quotes them, rocprofv3
+# Round 6, the committed measurements in one GPU session: HBM traffic passes on the final kernel sources, the bench line that quotes them, rocprofv3
 # kernel stats + the per-step summary with FLOP-weighted family lines, the per-launch step breakdown, SQ counters, anatomy, micro-benchmarks, the
-# three-stage chain.   usage: bash tools/gpu_r5_final.sh [name]
+# three-stage chain.   usage: bash tools/gpu_r6_final.sh [name]
 set -u
 REPO=$PWD
-OUT=$REPO/gpurun_out/${1:-r5_final}
+OUT=$REPO/gpurun_out/${1:-r6_final}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -36,4 +36,3 @@ rm -rf $OUT/step_a
 (timeout 300 python bench.py --no-cpu-baseline --no-vae --attn fp8 2>/dev/null) > $OUT/bench_attn_fp8.json
 (timeout 300 python bench.py --no-cpu-baseline --no-vae --batch 8 2>/dev/null) > $OUT/bench_batch8.json
 cut -c1-400 $OUT/bench.json; tail -12 $OUT/kernel_step_summary.txt; tail -4 $OUT/step_breakdown.txt; cat $OUT/three_stage.json | cut -c1-300
-(timeout 300 python -m pytest tests/test_kernels.py -m gpu -q -k "groupnorm_producer" 2>&1 | tail -3) > $OUT/rerun_producer_test.txt; cat $OUT/rerun_producer_test.txt

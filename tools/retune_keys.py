@@ -17,7 +17,8 @@ def main():
     from pcdms_amd import ops
     from pcdms_amd.unet import Stage2_InapintUNet2DConditionModel
     from tests.test_unet import _inputs, _kwargs
-    prefixes = [tuple(int(x) if x.lstrip("-").isdigit() else x for x in a.split(",")) for a in sys.argv[1:]]   # ("ln,11264,5120": the folded-LayerNorm keys)
+    write = "--write" in sys.argv           # put the re-tuned entries into the committed table
+    prefixes = [tuple(int(x) if x.lstrip("-").isdigit() else x for x in a.split(",")) for a in sys.argv[1:] if a != "--write"]   # ("ln,11264,5120": the folded-LayerNorm keys)
     old = {k: v for k, v in ops._TUNED.items() if any(k[: len(p)] == p for p in prefixes)}
     for k in old:
         del ops._TUNED[k]
@@ -32,6 +33,15 @@ def main():
     torch.cuda.synchronize()
     for k, v in old.items():
         print(",".join(str(x) for x in k), "old", v, "new", ops._TUNED.get(k))
+    if write:
+        import json
+        tab = json.loads(Path(ops.TUNING_FILE).read_text())
+        for k, v in old.items():
+            nv = ops._TUNED.get(k)
+            if nv is not None and tuple(nv) != tuple(v):
+                tab["gemm"][",".join(str(x) for x in k)] = list(nv)
+        Path(ops.TUNING_FILE).write_text(json.dumps(tab, indent=0))
+        print("wrote", ops.TUNING_FILE)
 
 
 if __name__ == "__main__":
