@@ -37,6 +37,25 @@ constexpr int KB = 64;     // keys per tile
 constexpr int QPW = 32;    // queries per wave
 constexpr int QPB = 128;   // queries per workgroup
 
+// XCD-aware placement of the (query block, head, batch) grid (round 6).  The hardware deals workgroups to the 8 XCDs round robin by their
+// linear id, so the 44 query blocks of one (batch, head) at N = 5632 -- which all stream the SAME 1.4 MB of K / V^T -- used to land on all
+// eight L2s: every XCD fetched every head's K / V^T across the fabric (rocprofv3 FETCH_SIZE, profiles/r5_kernel_traffic.json: 4.6 GB per
+// step for the 32 attention launches, ~ 850 MB per level-0 self-attention launch against 86 MB of q + k + v).  The bijection below (the
+// same one gemm_kernel uses) hands XCD x the x-th CONTIGUOUS eighth of the virtual ids, query block fastest: the ~ 96 workgroups resident
+// on an XCD then cover 2-3 heads, whose K / V^T (3-4 MB) live in that XCD's 4 MB L2.  flags bit 0 = 0: the plain grid (A/B switch).
+__device__ __forceinline__ void attn_block_coords(int flags, int& qb, int& h, int& b) {
+    if (!(flags & 1)) { qb = blockIdx.x; h = blockIdx.y; b = blockIdx.z; return; }
+    const int nqb = gridDim.x, H = gridDim.y;
+    const int total = nqb * H * (int)gridDim.z;
+    const int lin = blockIdx.x + nqb * (blockIdx.y + H * blockIdx.z);
+    const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int bh = v / nqb;
+    qb = v - bh * nqb;
+    b = bh / H;
+    h = bh - b * H;
+}
+
 // (Round 4 measured a software-pipelined form of this kernel -- the QK^T MFMAs of tile t + 1 issued in one scheduling region with the
 //  exponentials of tile t, [1 MFMA : 4 v_exp + 2 v_cvt_pk] placed by a sched_group_barrier pipeline, K one tile ahead of V^T in the ring, 32
 //  more accumulator registers => two workgroups per CU: 786-824 TF/s at N = 5632 against this kernel's 852-892 in the same session
@@ -54,7 +73,7 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
                                                          const u16* __restrict__ k, int64_t ldk,
                                                          const u16* __restrict__ vt, int64_t ldvt,
                                                          u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk,
-                                                         float c /* scale * log2(e) */, float thr /* lazy-rescale threshold, log2 units */) {
+                                                         float c /* scale * log2(e) */, float thr /* lazy-rescale threshold, log2 units */, int flags) {
     // K tile [64 keys][64 d] and V^T tile [64 d][64 keys], 2 stages each, unpadded 128-byte rows whose 16-byte
     // chunks are XOR-swizzled by (row>>1)&7 (applied on the DMA source offset and on the fragment reads, exactly
     // as in gemm.hip): conflict-free ds_read_b128, filled by buffer_load ... lds with no VGPR round trip.
@@ -62,8 +81,9 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
     __shared__ __attribute__((aligned(16))) u16 KV[2][2][KB * 64];   // [stage][K | V^T][row * 64 + col]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QPB + wave * QPW;
+    int qb, h, b;
+    attn_block_coords(flags, qb, h, b);
+    const int q0 = qb * QPB + wave * QPW;
     const int hh = lane >> 5, col = lane & 31;
 
     // Q fragments (B operand of S^T = K Q^T): lane -> query col, d = 16*ks + 8*hh + e
@@ -261,14 +281,15 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const u16* __restric
 __global__ __launch_bounds__(256, 3) void flash_attn_fp8_kernel(const u16* __restrict__ q, int64_t ldq, const uint8_t* __restrict__ k8,
                                                                 int64_t ldk, const uint8_t* __restrict__ vt8, int64_t ldvt,
                                                                 u16* __restrict__ o, int64_t ldo, int H, int Lq, int Lk, float c, float thr,
-                                                                float out_scale) {
+                                                                float out_scale, int flags) {
     // K tile [64 keys][64 B of d] and V^T tile [64 d][64 B of keys], 2 stages each; 64-byte rows, 16-byte chunks XOR-swizzled by
     // (row>>2)&3 on the DMA source and on the reads (four rows share a 256-byte bank row)
     __shared__ __attribute__((aligned(16))) uint8_t KV[2][2][KB * 64];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QPB + wave * QPW;
+    int qb, h, b;
+    attn_block_coords(flags, qb, h, b);
+    const int q0 = qb * QPB + wave * QPW;
     const int hh = lane >> 5, col = lane & 31;
 
     // Q operand (B of S^T = K Q^T): lane -> query col, its 32 bytes = d 32*hh .. +31, scaled to log2 units
@@ -440,6 +461,9 @@ __global__ __launch_bounds__(256, 3) void flash_attn_fp8_kernel(const u16* __res
 }
 }  // namespace
 
+// XCD-aware block placement (attn_block_coords): PCDM_ATTN_XCD=0 in the environment at load time = the plain grid (A/B switch)
+static int g_attn_xcd = [] { const char* e = getenv("PCDM_ATTN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+
 extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, int64_t ldk, const void* vt8, int64_t ldvt, void* o,
                                    int64_t ldo, int B, int H, int Lq, int Lk, float scale, float k_descale, float v_descale,
                                    float thr_log2, pcdm_stream_t s) {
@@ -449,7 +473,7 @@ extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, i
     if ((int64_t)Lk * ldk >= 0x7fffffffLL || (int64_t)64 * ldvt >= 0x7fffffffLL) return -2;  // 32-bit buffer offsets
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
     PCDM_LAUNCH(flash_attn_fp8_kernel, grid, dim3(256), 0, (hipStream_t)s, (const u16*)q, ldq, (const uint8_t*)k8, ldk, (const uint8_t*)vt8,
-                ldvt, (u16*)o, ldo, H, Lq, Lk, scale * k_descale * 1.44269504088896341f, thr_log2, v_descale);
+                ldvt, (u16*)o, ldo, H, Lq, Lk, scale * k_descale * 1.44269504088896341f, thr_log2, v_descale, g_attn_xcd);
     PCDM_CHECK_LAUNCH();
     return 0;
 }
@@ -469,7 +493,7 @@ extern "C" int pcdm_flash_attn_thr(const void* q, int64_t ldq, const void* k, in
     const dim3 grid((Lq + QPB - 1) / QPB, H, B);
 #define PCDM_ATTN_LAUNCH(RS)                                                                                                            \
     PCDM_LAUNCH(PCDM_KERNEL_NAME(flash_attn_kernel<RS>), grid, dim3(256), g_lds_pad, (hipStream_t)s, (const u16*)q, ldq, (const u16*)k, ldk, \
-                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2)
+                (const u16*)vt, ldvt, (u16*)o, ldo, H, Lq, Lk, scale * 1.44269504088896341f, thr_log2, g_attn_xcd)
     if (g_rowsum_valu) PCDM_ATTN_LAUNCH(true);
     else PCDM_ATTN_LAUNCH(false);
 #undef PCDM_ATTN_LAUNCH

@@ -24,6 +24,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 BF16 = torch.bfloat16
 LAUNCH_LOG: Optional[list] = None  # set to [] by bench.py to time individual launches with HIP events
 LAUNCH_KEYS: Optional[list] = None  # set to [] by tools/tune_in_step.py: (index into LAUNCH_LOG, tuning-table key) of every table-driven GEMM launch
+LAUNCH_SPANS: Optional[list] = None  # ... and ("ln" key, first, end) = the LAUNCH_LOG entries of every LayerNorm -> Linear pair
 AUTOTUNE = True                    # pick the GEMM tile configuration per problem shape at first use (GPU only)
 DEFER_SPLITK = os.environ.get("PCDM_DEFER_SPLITK", "1") != "0"   # split-K reduce folded into the consuming GroupNorm (A/B switch)
 
@@ -388,6 +389,20 @@ def row_stats_reference(a: torch.Tensor) -> torch.Tensor:
 
 
 def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile, row_stats=None, mode=None):
+    """(wrapper: records which entries of LAUNCH_LOG one LayerNorm -> Linear pair produced -- one launch or two, depending on the table -- for
+    tools/tune_in_step.py)"""
+    if LAUNCH_SPANS is None or LAUNCH_LOG is None:
+        return _gemm_ln_impl(a, pw, pw_ln, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0, tile=tile,
+                             row_stats=row_stats, mode=mode)
+    p0 = len(LAUNCH_LOG)
+    r = _gemm_ln_impl(a, pw, pw_ln, out, ln, ln_buf, rows_per_batch=rows_per_batch, epilogue=epilogue, out2=out2, vt_col0=vt_col0, tile=tile,
+                      row_stats=row_stats, mode=mode)
+    if not tile:
+        LAUNCH_SPANS.append((("ln", a.shape[0], pw.Npad, pw.K, epilogue), p0, len(LAUNCH_LOG)))
+    return r
+
+
+def _gemm_ln_impl(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, vt_col0, tile, row_stats=None, mode=None):
     """LayerNorm + GEMM: folded into the A-in-registers kernel (K = 320) or an extended instance of the tiled kernel when that wins for the
     shape, two launches otherwise.  Tuned choice per shape = (tile, mode): mode 1 = the kernel takes the row statistics itself, mode 2 = it
     merges the partials its producer wrote (``row_stats``; falls back to mode 1 on the same tile when the producer could not write them)."""
@@ -397,8 +412,6 @@ def _gemm_ln(a, pw, pw_ln, out, ln, ln_buf, *, rows_per_batch, epilogue, out2, v
     key = ("ln", M, pw.Npad, pw.K, epilogue)
     have_stats = row_stats_valid(row_stats)
     choice = (tile, mode or (2 if have_stats else 1)) if tile else _TUNED.get(key)   # (an explicit tile: partials are used when there are valid ones)
-    if LAUNCH_KEYS is not None and not tile:
-        LAUNCH_KEYS.append((-1, key))   # (occurrence marker: tools/tune_in_step.py also meets the pairs that run as two launches)
     if not LN_TILED and not tile and pw.K != 320:   # PCDM_LN_TILED=0: A/B switch -- levels 1-3 keep their LayerNorm launches
         pw_ln = None
     stream = _stream(a)

@@ -347,12 +347,12 @@ def test_c_context_starts_with_the_committed_tuning_table():
     from pcdms_amd.build import CSRC, ROOT, write_tuning_include
     before = (CSRC / "tuning_table.inc").read_text()
     assert write_tuning_include().read_text() == before, "csrc/tuning_table.inc is stale: run python -m pcdms_amd.build and commit it"
-    try:
-        lib = _lib.lib()
-    except RuntimeError:
+    if not torch.cuda.is_available():
+        # (no device: the HIP library loads but finds no gfx950 and -- by design -- starts on the heuristic; the emulator build stands in for
+        # the architecture.  Decided here, not by whichever library an earlier test left loaded: the test must pass when run alone.)
         from tests.emu import build_emu
         _lib.use_library(build_emu.load())
-        lib = _lib.lib()
+    lib = _lib.lib()
     cfg = _lib.UNetConfig()
     cfg.out_channels, cfg.n_levels, cfg.layers_per_block, cfg.cross_attention_dim, cfg.norm_groups, cfg.norm_eps = 4, 1, 1, 64, 32, 1e-5
     cfg.block_out_channels[0], cfg.heads[0], cfg.cross_attn[0] = 64, 1, 1
