@@ -274,7 +274,9 @@ int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s);
  * Weight names (N = diffusers module path, e.g. "down_blocks.0.resnets.1." / "...attentions.0."):
  *   conv_in, conv_out, N"conv1", N"conv2", N"conv_shortcut", "down_blocks.i.downsamplers.0.conv", "up_blocks.i.upsamplers.0.conv"  (pcdm_pack conv3x3 / linear)
  *   N"proj_in", N"proj_out", N"qkv" (to_q|to_k|to_v rows), N"o1", N"q2", N"kv2" (to_k|to_v of attn2), N"o2", N"ff1" (GEGLU packing), N"ff2",
- *   optional N"qkv_ln" / N"q2_ln" / N"ff1_ln" (LayerNorm folded, with wsum), "time_emb_proj" (all resnets' rows concatenated in resnet order),
+ *   optional N"qkv_ln" / N"q2_ln" / N"ff1_ln" (LayerNorm folded, with wsum), optional N"ffo" = [Wp W2 | Wp] with bias Wp b2 + bp (W2, b2 = ff.net.2;
+ *   Wp, bp = proj_out; N = C, K = 5 C: when registered, ff.net.2 (+ residual) -> proj_out (+ residual) of that block run as ONE two-source GEMM),
+ *   "time_emb_proj" (all resnets' rows concatenated in resnet order),
  *   "time_embedding.linear_1/2", "class_embedding.linear_1/2" (bf16 [N, K] unpadded + fp32 bias, for pcdm_small_linear)
  * Vectors (fp32): N"norm1.weight" / ".bias", N"norm2.*" (resnets), N"norm.*" and N"transformer_blocks.0.norm{1,2,3}.*" (transformers),
  *   "conv_norm_out.weight" / ".bias".

@@ -234,7 +234,9 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.step_error = g.step_error;
         const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : (g.dup_rows ? 2 : 0)};
         auto it = u->tiles.find(key);
-        if (it != u->tiles.end()) {
+        // (a table entry that names the A-in-registers kernel for a call it cannot serve -- row vector, fewer residual rows than M -- is skipped:
+        //  the key does not carry those; pcdms_amd.ops.gemm does the same)
+        if (it != u->tiles.end() && !(it->second.first >= 31 /* the A-in-registers tiles: pcdm.h */ && (g.rowvec || (g.residual && g.res_mod < M)))) {
             p.tile = it->second.first;
             if (it->second.second > 1) {
                 p.split_k = it->second.second;
@@ -809,6 +811,16 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             const PW* wl = u->w.count(p + "ff1_ln") ? &u->w[p + "ff1_ln"] : nullptr;
             R.gemm_ln(R.buf("t0"), cc, M, R.pw(p + "ff1"), wl, R.vec(b + "norm3.weight"), R.vec(b + "norm3.bias"), 1e-5f, R.buf("ln"), R.buf("ff"), g);
         }
+        void* out = R.buf(out_name);
+        if (u->w.count(p + "ffo")) {
+            // ff.net.2 (+ residual) -> proj_out (+ residual) as one two-source GEMM over [ff | t0] against [Wp W2 | Wp] (composed at load time by the
+            // host: pcdms_amd/unet.py FUSE_FF_OUT; registered as "<transformer>ffo"): no launch and no M x C round trip for the state in between
+            Run::G g;
+            g.a2 = R.buf("t0"); g.lda2 = cc;
+            g.residual = x; g.ldr = cc; g.res_mod = M;
+            R.gemm(R.buf("ff"), 4 * cc, M, R.pw(p + "ffo"), out, g);
+            return out;
+        }
         {
             Run::G g;
             g.residual = R.buf("t0"); g.ldr = cc; g.res_mod = M;
@@ -816,7 +828,6 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         }
         Run::G g;
         g.residual = x; g.ldr = cc; g.res_mod = M;
-        void* out = R.buf(out_name);
         R.gemm(R.buf("t1"), cc, M, R.pw(p + "proj_out"), out, g);
         return out;
     };

@@ -325,7 +325,11 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
                a2 is not None, residual is not None) + ((True,) if zero_rows else ((2,) if dup_rows else ()))   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
-        if tile == 0 and a.is_cuda and not torch.cuda.is_current_stream_capturing():   # (the emulator build runs the library's heuristic)
+        if tile in ROWGEMM_TILES and (rowvec is not None or act != ACT_NONE or (residual is not None and res_mod < M)):
+            # the key does not carry these (none of the UNet's K = 320 residual linears has them): the A-in-registers kernel the table names for the
+            # shape cannot serve this call -- the library's heuristic tile does (a table entry is a preference, never a reason to refuse a launch)
+            tile, split = 0, 1
+        elif tile == 0 and a.is_cuda and not torch.cuda.is_current_stream_capturing():   # (the emulator build runs the library's heuristic)
             tile, split = _TUNED[key] = _autotune(p, stream, pw, epilogue, a.device, out)
     elif split_k > 1:
         split = split_k

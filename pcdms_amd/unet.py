@@ -33,6 +33,13 @@ from .ops import BF16, PackedWeight
 
 SHARE_CFG_PREFIX = os.environ.get("PCDM_SHARE_CFG_PREFIX", "1") != "0"   # A/B switch (tools/README.md)
 TIME_TABLE = os.environ.get("PCDM_TIME_TABLE", "1") != "0"               # A/B switch: time embeddings of all steps with the conditioning
+# ff.net.2 (+ residual) -> proj_out (+ residual) as ONE two-source GEMM (round 6).  Nothing non-linear sits between the two Linears
+# (diffusers BasicTransformerBlock / Transformer2DModel as composed at stage2_inpaint_unet_2d_condition.py:321-361,407-430):
+#     proj_out(ff2(g) + h2) + x  =  g (Wp W2)^T + h2 Wp^T + (Wp b2 + bp) + x
+# so the block's tail is a GEMM over the channel concat [g | h2] (K = 4C + C) against [Wp W2 | Wp], composed once at load time in fp64 and
+# rounded to bf16 like any weight: the same 2 M C 5C FLOPs, one launch instead of two, and the block's last residual state (h3: M x C bf16)
+# is neither written nor read back.  PCDM_FUSE_FF_OUT=0: the two launches (A/B switch, tools/README.md).
+FUSE_FF_OUT = os.environ.get("PCDM_FUSE_FF_OUT", "1") != "0"
 
 _DEFAULT_CONFIG: Dict[str, Any] = dict(
     sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
@@ -361,6 +368,10 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             a["o2"] = lin(b + "attn2.to_out.0.")
             a["ff1"] = ops.pack_geglu(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"], dev)
             a["ff2"] = lin(b + "ff.net.2.")
+            if FUSE_FF_OUT:
+                w2, b2 = sd[b + "ff.net.2.weight"].double(), sd[b + "ff.net.2.bias"].double()
+                wp, bp = sd[p + "proj_out.weight"].double().reshape(c, c), sd[p + "proj_out.bias"].double()
+                a["ffo"] = ops.pack_linear(torch.cat([wp @ w2, wp], 1).float(), (wp @ b2 + bp).float(), dev)
             if True:   # second copies of the three LayerNorm-fed linears with the LayerNorm FOLDED into the weights: K = 320 -> the
                        # A-in-registers kernel (rowgemm.hip); K = 640 / 1280 (round 5) -> the LNF instances of the tiled kernel (gemm.hip)
                 ln = [(sd[b + f"norm{i}.weight"], sd[b + f"norm{i}.bias"]) for i in (1, 2, 3)]
@@ -695,6 +706,8 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             # GEGLU feed-forward
             ff = ops.gemm(t2, a["ff1"], self._buf("ff", (M, 4 * c)), epilogue=ops.EPI_GEGLU, ln=(a["ln3"][0], a["ln3"][1], 1e-5),
                           ln_buf=self._buf("ln", (M, c)), pw_ln=a.get("ff1_ln"), row_stats=rs)
+            if "ffo" in a:   # ff.net.2 + residual and proj_out + residual as one contraction over [ff | t2] (FUSE_FF_OUT above)
+                return ops.gemm(ff, a["ffo"], self._buf(name, (M, c)), a2=t2, residual=x, res_mod=M)
             t3 = ops.gemm(ff, a["ff2"], self._buf("t1", (M, c)), residual=t2, res_mod=M)
             return ops.gemm(t3, a["proj_out"], self._buf(name, (M, c)), residual=x, res_mod=M)
 

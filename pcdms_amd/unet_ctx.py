@@ -92,7 +92,7 @@ class UNetContext:
             self._set_v(p + "norm2", r["n2"])
         for p, _, _ in _transformers(u):
             a = W[p]
-            for k in ("proj_in", "proj_out", "qkv", "o1", "q2", "kv2", "o2", "ff1", "ff2", "qkv_ln", "q2_ln", "ff1_ln"):
+            for k in ("proj_in", "proj_out", "qkv", "o1", "q2", "kv2", "o2", "ff1", "ff2", "ffo", "qkv_ln", "q2_ln", "ff1_ln"):
                 if k in a:
                     self._set_w(p + k, a[k])
             self._set_v(p + "norm", a["norm"])

@@ -255,6 +255,30 @@ def test_gemm_linear_bias_residual_rowvec(backend):
         close(out, ref)
 
 
+def test_table_named_rowgemm_tile_is_a_preference(backend, monkeypatch):
+    """The tuning key carries neither the row vector nor res_mod.  When the table names the A-in-registers kernel (tiles 31..36: K = 320, no
+    row vector, residual rows for every output row) for a shape and a call of that shape asks for more, the launch takes the library's
+    heuristic tile instead of failing -- round 6's in-step pass moved the (45056, 320, 320) + residual key to tile 34 and the full-size
+    row-vector case of test_gemm_linear_bias_residual_rowvec was refused (-1) until ops.gemm / unet_ctx.hip learnt this."""
+    dev = backend.device
+    M, K, N = (96, 320, 64) if backend.is_emu else (45056, 320, 320)
+    a, w = rnd(M, K, seed=210), rnd(N, K, seed=211, scale=1 / math.sqrt(K))
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(212))
+    res, rowvec = rnd(M, N, seed=213), torch.randn(2, N, generator=torch.Generator().manual_seed(214))
+    pw = ops.pack_linear(w.float(), bias, dev)
+    key = (M, pw.Npad, K, 0, 0, 0, ops.EPI_STORE, False, True)
+    monkeypatch.setitem(ops._TUNED, key, (34, 1))
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(a.to(dev), pw, out, rowvec=rowvec.to(dev), rows_per_batch=M // 2, residual=res.to(dev), res_mod=M)
+    backend.sync()
+    close(out, a.float() @ w.float().t() + bias + res.float() + rowvec.repeat_interleave(M // 2, 0))
+    # ... and without the row vector the table's tile runs (same key)
+    out2 = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(a.to(dev), pw, out2, residual=res.to(dev), res_mod=M)
+    backend.sync()
+    close(out2, a.float() @ w.float().t() + bias + res.float())
+
+
 def test_gemm_split_k(backend):
     """K split over several workgroups per tile + fp32 reduce kernel (small-M / huge-K level-3 convs)."""
     dev = backend.device

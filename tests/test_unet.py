@@ -105,6 +105,55 @@ def test_unet_tiny(backend):
     _check(o2, unet_forward(sd, cfg, s2, 500, e, c, p))
 
 
+def test_ff_out_fusion_matches_the_two_launches(backend, monkeypatch):
+    """``ff.net.2 (+ residual) -> proj_out (+ residual)`` as one two-source GEMM against [Wp W2 | Wp] (pcdms_amd/unet.py FUSE_FF_OUT; the Linears
+    composed at stage2_inpaint_unet_2d_condition.py:321-361): the composed weight is the exact product of the two layers (fp64 check), a
+    model packed with the fusion launches one GEMM fewer per transformer block, both forms stay inside the forward tolerance against the
+    fp32 oracle, and the fused form is no further from it than the two launches (it skips one bf16 rounding of the residual state)."""
+    from pcdms_amd import ops, unet as U
+    cfg = UNetConfig.tiny()
+    B, h, w, L = (2, 8, 8, 5) if backend.is_emu else (4, 16, 24, 10)
+    sd = synth_state_dict(cfg, seed=0, random_affine=True)
+    s, e, c, p = _inputs(cfg, B, h, w, L)
+    dev = backend.device
+    outs, launches = {}, {}
+    for fused in (True, False):
+        monkeypatch.setattr(U, "FUSE_FF_OUT", fused)
+        m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+        m.load_state_dict(sd)
+        m.to(dev)
+        m._pack()
+        blocks = [a for a in m._w.values() if isinstance(a, dict) and "ff2" in a]
+        assert blocks and all(("ffo" in a) == fused for a in blocks)
+        if fused:   # [Wp W2 | Wp], bias Wp b2 + bp -- to bf16 rounding of the packed copy
+            a = blocks[0]
+            pre = next(k for k, v in m._w.items() if v is a)
+            w2, b2 = sd[pre + "transformer_blocks.0.ff.net.2.weight"].double(), sd[pre + "transformer_blocks.0.ff.net.2.bias"].double()
+            wp, bp = sd[pre + "proj_out.weight"].double().reshape(a["c"], a["c"]), sd[pre + "proj_out.bias"].double()
+            ref_w = torch.cat([wp @ w2, wp], 1)
+            got = a["ffo"].w.float().cpu()[: a["c"]].double()
+            assert got.shape == ref_w.shape and ((got - ref_w).norm() / ref_w.norm()).item() < 4e-3
+            assert torch.allclose(a["ffo"].bias.cpu()[: a["c"]].double(), wp @ b2 + bp, atol=1e-6)
+        count = {"n": 0}
+        orig_gemm = ops.gemm
+
+        def counting(*args, **kw):
+            count["n"] += 1
+            return orig_gemm(*args, **kw)
+        monkeypatch.setattr(ops, "gemm", counting)
+        out = m(s.to(dev), torch.tensor(981, device=dev), e.to(dev), class_labels=c.to(dev), my_pose_cond=p.to(dev), return_dict=False)[0]
+        backend.sync()
+        monkeypatch.setattr(ops, "gemm", orig_gemm)
+        outs[fused], launches[fused] = out.float().cpu(), count["n"]
+    n_blocks = len(blocks)
+    assert launches[False] - launches[True] == n_blocks, (launches, n_blocks)
+    ref = unet_forward(sd, cfg, s, torch.tensor(981), e, c, p)
+    rel_f, _ = _check(outs[True], ref)
+    rel_u, _ = _check(outs[False], ref)
+    assert rel_f <= rel_u * 1.25 + 1e-4, (rel_f, rel_u)
+    assert ((outs[True] - outs[False]).norm() / outs[False].norm()).item() < 1e-2
+
+
 @pytest.mark.gpu
 def test_unet_latent_not_divisible_by_8(gpu_backend):
     """Latent 20x11 (like the stage-3 latent 64x44 of a 352-wide image): the stride-2 convs round up (11 -> 6 -> 3 -> 2) and

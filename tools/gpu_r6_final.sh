@@ -28,6 +28,12 @@ timeout 200 rocprofv3 --kernel-trace --pmc $A --output-format csv -d $OUT/step_a
 cd $REPO
 python tools/pmc_summary.py $OUT/step_a $OUT/step_a > $OUT/pmc_step.json 2>$OUT/pmc_step.err
 rm -rf $OUT/step_a
+cd /tmp
+for x in 0 1; do
+PCDM_ATTN_XCD=$x timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_attn_fetch_$x -- python $REPO/tools/pmc_attn.py > /dev/null 2>&1
+done
+cd $REPO
+for x in 0 1; do python tools/pmc_attn_fetch.py $OUT/pmc_attn_fetch_$x > $OUT/attn_fetch_xcd$x.json 2> $OUT/attn_fetch_xcd$x.err; rm -rf $OUT/pmc_attn_fetch_$x; done
 (timeout 120 python tools/gemm_anatomy.py 2>&1 | grep -v amdgpu.ids) > $OUT/gemm_anatomy.txt
 (timeout 120 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids) > $OUT/bench_attn.txt
 (timeout 120 python tools/bench_gn.py 2>&1 | grep -v amdgpu.ids) > $OUT/bench_gn.txt
@@ -35,4 +41,7 @@ rm -rf $OUT/step_a
 (timeout 400 python tools/bench_three_stage.py 2>&1 | grep -v amdgpu.ids | tail -3) > $OUT/three_stage.json
 (timeout 300 python bench.py --no-cpu-baseline --no-vae --attn fp8 2>/dev/null) > $OUT/bench_attn_fp8.json
 (timeout 300 python bench.py --no-cpu-baseline --no-vae --batch 8 2>/dev/null) > $OUT/bench_batch8.json
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $OUT/gpu_tests.txt
+(timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2) > $OUT/smoke.txt
+cat $OUT/attn_fetch_xcd0.json $OUT/attn_fetch_xcd1.json; cat $OUT/gpu_tests.txt $OUT/smoke.txt
 cut -c1-400 $OUT/bench.json; tail -12 $OUT/kernel_step_summary.txt; tail -4 $OUT/step_breakdown.txt; cat $OUT/three_stage.json | cut -c1-300

@@ -264,8 +264,18 @@ def main():
           f"output rel diff {float((lat1 - lat_ref).norm() / lat_ref.norm()):.2e}", flush=True)
     Path(args.out).parent.mkdir(exist_ok=True)
     Path(args.out).write_text(json.dumps({"changed": changed, "total_ms_before": total0, "total_ms_after": sum(ms1), "report": report}, indent=1))
-    if args.write and changed:
+    # keys of this step the committed table does not know yet (the online autotuner chose them at first use; the passes above kept or changed them)
+    tab_now = json.loads(Path(ops.TUNING_FILE).read_text())["gemm"] if Path(ops.TUNING_FILE).exists() else {}
+    added = {}
+    for key in list(by_key) + list(ln_keys):
+        ks = ",".join(str(x) for x in key)
+        if ks not in tab_now and ks not in changed and key in ops._TUNED:
+            added[ks] = list(ops._TUNED[key])
+    if added:
+        print(f"{len(added)} keys of this step are new to the table:", ", ".join(f"{k} -> {v[0]}/{v[1]}" for k, v in sorted(added.items())), flush=True)
+    if args.write and (changed or added):
         tab = json.loads(Path(ops.TUNING_FILE).read_text())
+        tab["gemm"].update(added)
         tab["gemm"].update(changed)
         tab["note"] = (tab.get("note", "") + " | round 6: entries re-tuned IN THE STEP by tools/tune_in_step.py").strip()
         Path(ops.TUNING_FILE).write_text(json.dumps(tab, indent=0))
