@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* pcdm_stream_t; /* hipStream_t */
 
-#define PCDM_ABI_VERSION 4   /* what pcdm_version() returns for the library this header belongs to */
+#define PCDM_ABI_VERSION 5   /* what pcdm_version() returns for the library this header belongs to */
 int pcdm_version(void);
 /* 1 only for the test-only CPU lane emulator build (tests/emu); the product .so returns 0. */
 int pcdm_is_emulator(void);
@@ -158,8 +158,15 @@ typedef struct pcdm_gemm_params {
                                    the device (the launch stays inside the caller's memory) and, if step_error is non-NULL, *step_error is set to 1 -- the
                                    host reads it when it next synchronises (pcdm_unet_step_overflow for the UNet context).  0: unchecked (ABI <= 3 behaviour) */
     int32_t* step_error;        /* DEVICE int32, written only on an out-of-range step (never cleared by the library) */
+    const void* a3;             /* conv3x3 with EXTRA K (ABI 5): K = 9 cin + cx, cx > 0 -- behind the nine taps the contraction runs on over a 1x1 convolution of
+                                   up to two more NHWC bf16 tensors of the OUTPUT geometry: a2 [M, lda2] supplies the first c1 channels, a3 [M, lda3] the
+                                   other cx - c1 (NULL when c1 == cx); W rows are [9 cin taps | c1 | cx - c1].  ResnetBlock2D.conv_shortcut over the block's
+                                   (concatenated) input composed into conv2 (resnet.py as composed at stage2_inpaint_unet_2d_condition.py:321-344,407-430):
+                                   no shortcut launch, no residual round trip.  stride 1, no upsample, Hi == Ho, Wi == Wo, symmetric padding, no dup_rows;
+                                   c1, cx multiples of 64; lda2 >= c1, lda3 >= cx - c1, both multiples of 8; else -1 */
+    int64_t lda3;
 } pcdm_gemm_params;
-/* pcdm_version() == 4: the struct above STARTS with struct_size and ends with rowvec_step_count, step_error (3: no struct_size, ended with
+/* pcdm_version() == 5: the struct above STARTS with struct_size and ends with a3, lda3 (4: ended with rowvec_step_count, step_error; 3: no struct_size, ended with
  * ln_row_stats, row_stats_out, gn_stats_out, gn_stats_gs -- the last two are gone with the GroupNorm-statistics producer; 2: ended with
  * dup_rows; 1: with ln_eps).  Zero-initialise it (memset), set struct_size = sizeof(pcdm_gemm_params): the library compares it with its own and
  * returns -1 on a mismatch, so a host built against another header fails at its first call instead of having trailing fields misread.
@@ -272,7 +279,8 @@ int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s);
  * sampling call pcdm_unet_prepare_conditioning (class embedding, pose feature, cross-attention K / V^T: step-invariant) and per denoise
  * step pcdm_unet_forward.  No allocation inside, every launch on the caller's stream, fixed scratch addresses (hipGraph-capturable).
  * Weight names (N = diffusers module path, e.g. "down_blocks.0.resnets.1." / "...attentions.0."):
- *   conv_in, conv_out, N"conv1", N"conv2", N"conv_shortcut", "down_blocks.i.downsamplers.0.conv", "up_blocks.i.upsamplers.0.conv"  (pcdm_pack conv3x3 / linear)
+ *   conv_in, conv_out, N"conv1", N"conv2", N"conv_shortcut", optional N"conv2s" (conv2's packed rows with conv_shortcut's [N, Cx] appended along K,
+ *   bias = the sum: when registered, conv2 + conv_shortcut of that resnet run as ONE launch through pcdm_gemm_params.a2 / a3), "down_blocks.i.downsamplers.0.conv", "up_blocks.i.upsamplers.0.conv"  (pcdm_pack conv3x3 / linear)
  *   N"proj_in", N"proj_out", N"qkv" (to_q|to_k|to_v rows), N"o1", N"q2", N"kv2" (to_k|to_v of attn2), N"o2", N"ff1" (GEGLU packing), N"ff2",
  *   optional N"qkv_ln" / N"q2_ln" / N"ff1_ln" (LayerNorm folded, with wsum), optional N"ffo" = [Wp W2 | Wp] with bias Wp b2 + bp (W2, b2 = ff.net.2;
  *   Wp, bp = proj_out; N = C, K = 5 C: when registered, ff.net.2 (+ residual) -> proj_out (+ residual) of that block run as ONE two-source GEMM),

@@ -44,6 +44,7 @@ class GemmParams(C.Structure):
         ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
         ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64), ("dup_rows", C.c_int32),
         ("ln_row_stats", C.c_void_p), ("row_stats_out", C.c_void_p), ("rowvec_step_count", C.c_int32), ("step_error", C.c_void_p),
+        ("a3", C.c_void_p), ("lda3", C.c_int64),
     ]
 
     def __init__(self, *args, **kw):

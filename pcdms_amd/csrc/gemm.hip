@@ -106,7 +106,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     // 32-bit buffer offsets: every operand must stay below 2 GiB
     const int64_t lim = 0x7fffffffLL;
     if ((int64_t)p->Npad * (p->ldw > 0 ? p->ldw : p->K) * 2 >= lim) return -2;
-    if (p->conv ? ((int64_t)p->B * p->Hi * p->Wi * p->cin * 2 + ((int64_t)p->Wi + 1) * p->cin * 2 >= lim)
+    if (p->conv ? ((int64_t)p->B * p->Hi * p->Wi * p->cin * 2 + ((int64_t)p->Wi + 1) * p->cin * 2 >= lim ||
+                   (p->a2 && (int64_t)p->M * p->lda2 * 2 >= lim) || (p->a3 && (int64_t)p->M * p->lda3 * 2 >= lim))
                 : ((int64_t)p->M * p->lda * 2 >= lim || (p->a2 && (int64_t)p->M * p->lda2 * 2 >= lim))) return -2;
     const int64_t out_esz = p->epilogue == PCDM_EPI_NCHW_F32 ? 4 : 2;   // (fp32 only there; the x4 applied to every epilogue refused the
                                                                          //  VAE decoder's 2.9 M x 256 bf16 upsampling convs at 8 samples)
@@ -118,6 +119,9 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.lda = p->lda;
     a.lda2 = p->lda2;
     a.c1 = p->a2 ? p->c1 : p->K;
+    a.a3 = (const u16*)p->a3;
+    a.lda3 = p->lda3;
+    a.xinv = 0;
     a.B = p->B; a.Hi = p->Hi; a.Wi = p->Wi; a.Ho = p->Ho; a.Wo = p->Wo;
     a.stride = p->stride; a.upsample = p->upsample; a.cin = p->cin;
     a.pad = p->no_pad_lo ? 0 : 1;
@@ -167,11 +171,18 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         if (p->ws_floats < (int64_t)a.split_k * p->M * p->Npad) return -1;
     }
     if (p->conv) {
-        if (p->cin % BK || p->K != 9 * p->cin || (p->stride != 1 && p->stride != 2) || p->a2) return -1;
+        const int cx = p->K - 9 * p->cin;   // extra K behind the nine taps: a 1x1 convolution over a2 [+ a3] at the output pixel (pcdm_gemm_params.a3)
+        if (p->cin <= 0 || p->cin % BK || cx < 0 || (p->stride != 1 && p->stride != 2)) return -1;
+        if (cx == 0 ? (p->a2 || p->a3)
+                    : (!p->a2 || p->stride != 1 || p->upsample || p->no_pad_lo || p->dup_rows || p->Hi != p->Ho || p->Wi != p->Wo || cx % BK ||
+                       p->c1 <= 0 || p->c1 % BK || p->c1 > cx || (p->c1 < cx) != (p->a3 != nullptr) || p->lda2 < p->c1 || (p->lda2 & 7) ||
+                       (p->a3 && (p->lda3 < cx - p->c1 || (p->lda3 & 7))) || (((uintptr_t)p->a2 | (uintptr_t)p->a3) & 15)))
+            return -1;
+        a.xinv = (uint32_t)(((1ull << 31) + (uint64_t)(p->cin / 64) - 1) / (uint64_t)(p->cin / 64));   // m = ((a_off >> 7) * xinv) >> 31: exact for a_off < 2^31
         if (p->upsample && (p->stride != 1 || p->no_pad_lo || p->Ho < p->Hi || p->Wo < p->Wi)) return -1;
         if (p->M != p->B * p->Ho * p->Wo) return -1;
     } else {
-        if (p->a2 && (p->c1 % BK || p->c1 <= 0 || p->c1 >= p->K)) return -1;
+        if (p->a3 || (p->a2 && (p->c1 % BK || p->c1 <= 0 || p->c1 >= p->K))) return -1;
     }
     if (p->epilogue == PCDM_EPI_GEGLU && (!p->bias || p->Npad % 128 || p->N * 2 > p->Npad)) return -1;
     if (p->epilogue == PCDM_EPI_SPLIT_VT && (!p->out2 || p->vt_col0 % 4)) return -1;

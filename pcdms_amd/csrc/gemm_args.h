@@ -10,6 +10,9 @@ struct GemmArgs {
     const u16* a2;
     int64_t lda, lda2;
     int c1;
+    const u16* a3;     // conv with extra K (K = 9 cin + cx): the 1x1 sources behind the taps are a2 (c1 channels) and a3 (cx - c1); pcdm_gemm_params.a3
+    int64_t lda3;
+    uint32_t xinv;     // ceil(2^31 / (cin / 64)): pixel index of a conv row from its centre-tap offset (gemm_kernel.inc issue_tile)
     int B, Hi, Wi, Ho, Wo, stride, upsample, cin;
     int pad;   // conv: 1 = symmetric zero padding 1 (default); 0 = bottom/right only (VAE encoder Downsample2D)
     const u16* w;

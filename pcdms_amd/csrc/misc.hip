@@ -352,7 +352,7 @@ __global__ void advance_step_kernel(int32_t* step) {
 inline dim3 grid1d(int64_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 }  // namespace
 
-extern "C" int pcdm_version(void) { return PCDM_ABI_VERSION; }   // 4: pcdm_gemm_params starts with struct_size, ends with rowvec_step_count / step_error (include/pcdm.h)
+extern "C" int pcdm_version(void) { return PCDM_ABI_VERSION; }   // 5: pcdm_gemm_params starts with struct_size, ends with a3 / lda3 (include/pcdm.h)
 extern "C" int pcdm_is_emulator(void) {
 #ifdef PCDM_EMU
     return 1;

@@ -85,6 +85,13 @@ __device__ __forceinline__ void glds_wait() {
 // ---- LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds) ------------------------
 // address = base + voff (per lane, VGPR) + soff (wave-uniform, SGPR); lanes whose voff has bit 31 set are out
 // of range: the hardware bounds check makes them deliver ZEROS (no branch, no separate zero source).
+// an optimisation barrier on one VGPR value: what is computed from it afterwards cannot be hoisted out of the enclosing loop (rarely taken
+// branches of a register-bound loop: the loop-invariant code motion of their address arithmetic would cost the common path live registers)
+#ifdef PCDM_EMU
+#define PCDM_LOOP_VARIANT(x) ((void)0)
+#else
+#define PCDM_LOOP_VARIANT(x) asm volatile("" : "+v"(x))
+#endif
 #ifdef PCDM_EMU
 struct BufRsrc { const char* base; uint32_t size; };
 __device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, uint32_t bytes = 0x7fffffffu) { return BufRsrc{(const char*)p, bytes}; }

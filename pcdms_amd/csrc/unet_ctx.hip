@@ -167,6 +167,9 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
     struct G {   // optional arguments of gemm()
         const void* a2 = nullptr;
         int64_t lda2 = 0;
+        const void* a3 = nullptr;   // conv with extra K (pcdm_gemm_params.a3): a2 [M, c1] and a3 [M, cx - c1] are the 1x1 sources behind the taps
+        int64_t lda3 = 0;
+        int c1 = 0;                 // ... and c1 the channels a2 supplies (0: linear two-source, c1 = lda)
         const float* rowvec = nullptr;
         int64_t ldrv = 0;
         int rows_per_batch = 0;
@@ -203,9 +206,11 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.struct_size = (uint32_t)sizeof(p);
         p.a = a;
         p.lda = lda;
-        p.c1 = g.a2 ? (int)lda : w->K;
+        p.c1 = g.c1 ? g.c1 : (g.a2 ? (int)lda : w->K);
         p.a2 = g.a2;
         p.lda2 = g.lda2;
+        p.a3 = g.a3;
+        p.lda3 = g.lda3;
         p.conv = g.conv;
         if (g.conv) {
             p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi; p.Ho = g.Ho; p.Wo = g.Wo;
@@ -733,6 +738,19 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
         }
         R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
+        if (u->w.count(p + "conv2s")) {
+            // conv2 + conv_shortcut as ONE contraction (weight rows [9 cout taps | C1 | C2], composed by the host: pcdms_amd/unet.py FUSE_SHORTCUT;
+            // registered as "<resnet>conv2s"): the block's input enters through the extra K, no shortcut launch, no residual
+            Run::G g2;
+            g2.conv = 1; g2.B = B; g2.Hi = hh; g2.Wi = ww; g2.Ho = hh; g2.Wo = ww;
+            g2.a2 = x1; g2.lda2 = C1; g2.c1 = C1;
+            if (x2) { g2.a3 = x2; g2.lda3 = C2; }
+            g2.rows_per_batch = HW_;
+            g2.defer = gn_next ? 1 : 0;
+            void* out = R.buf(out_name);
+            R.gemm(R.buf("gn"), cout, M, R.pw(p + "conv2s"), out, g2);
+            return out;
+        }
         const void* res = x1;
         if (u->w.count(p + "conv_shortcut")) {
             Run::G gs;

@@ -189,6 +189,25 @@ def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, pad_to: 
     return pw
 
 
+def pack_conv3x3_shortcut(w: torch.Tensor, bias: Optional[torch.Tensor], w_sc: torch.Tensor, bias_sc: Optional[torch.Tensor], device) -> PackedWeight:
+    """ResnetBlock2D's conv2 [N, C, 3, 3] and conv_shortcut [N, Cx(,1,1)] as ONE contraction: rows [9 C_pad taps | Cx], bias = the sum.  The
+    launch reads conv2's input through the taps and the block's input (one tensor or the two halves of the skip concat) through the extra K
+    (``gemm(..., conv=..., a2=, a3=)``): out = conv2(h) + conv_shortcut(x), exactly the residual sum of resnet.py's forward."""
+    N, Cin = w.shape[:2]
+    Cp = _round_up(Cin, 64)
+    wp = torch.zeros(N, 3, 3, Cp, dtype=torch.float32)
+    wp[..., :Cin] = w.float().permute(0, 2, 3, 1)
+    ws = w_sc.reshape(N, -1).float()
+    assert ws.shape[1] % 64 == 0, ws.shape
+    b = None
+    if bias is not None or bias_sc is not None:
+        b = (bias.float() if bias is not None else 0) + (bias_sc.float() if bias_sc is not None else 0)
+    pw = pack_linear(torch.cat([wp.reshape(N, 9 * Cp), ws], 1), b, device)
+    pw.cin = Cp
+    pw.alg_nk = N * (9 * Cin + ws.shape[1])
+    return pw
+
+
 def pack_geglu(w: torch.Tensor, bias: torch.Tensor, device) -> PackedWeight:
     """GEGLU proj weight [2*D, K] (rows [h | gate]) -> rows interleaved per 64 as [32 h | 32 gate]."""
     w = w.float()
@@ -231,7 +250,7 @@ def pack_geglu_ln(w, bias, gamma, beta, device) -> PackedWeight:
 
 
 # ------------------------------------------------------------------------------------ GEMM / conv
-def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
+def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None, a3: Optional[torch.Tensor] = None,
          rowvec: Optional[torch.Tensor] = None, rows_per_batch: Optional[int] = None,
          residual: Optional[torch.Tensor] = None, res_mod: int = 0, epilogue: int = EPI_STORE,
          out2: Optional[torch.Tensor] = None, vt_col0: int = 0, conv: Optional[dict] = None, tile: int = 0,
@@ -241,7 +260,9 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None, rowvec_step_count: int = 0,
          step_error: Optional[torch.Tensor] = None) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
-    NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.
+    NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.  A convolution whose packed weight has EXTRA K behind the nine
+    taps (``pack_conv3x3_shortcut``: K = 9 cin + cx) contracts on over a 1x1 convolution of ``a2`` [M, c1] (and ``a3`` [M, cx - c1]) at the
+    output pixel -- ResnetBlock2D's conv2 + conv_shortcut over the block's (concatenated) input as one launch (pcdm_gemm_params.a3, ABI 5).
 
     ``ln=(gamma, beta, eps)``: out = epilogue(LayerNorm(A) @ W^T).  With ``pw_ln`` (the same Linear packed by ``pack_linear_ln`` /
     ``pack_geglu_ln``: LayerNorm folded into the weights) no LayerNorm pass is needed at all: the A-in-registers kernel (tiles 31..36, K = 320; 34
@@ -276,10 +297,22 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.no_pad_lo = conv.get("no_pad_lo", 0)
         assert a.numel() == p.B * p.Hi * p.Wi * pw.cin, (a.shape, pw.cin)
         M = p.B * p.Ho * p.Wo
+        if a2 is not None:   # extra K: the 1x1 sources behind the taps
+            assert a2.dtype == BF16 and a2.dim() == 2 and a2.shape[0] == M and a2.stride(-1) == 1
+            p.a2, p.lda2, p.c1 = _ptr(a2), a2.stride(0), a2.shape[1]
+            cx = a2.shape[1]
+            if a3 is not None:
+                assert a3.dtype == BF16 and a3.dim() == 2 and a3.shape[0] == M and a3.stride(-1) == 1
+                p.a3, p.lda3 = _ptr(a3), a3.stride(0)
+                cx += a3.shape[1]
+            assert pw.K == 9 * pw.cin + cx, (pw.K, pw.cin, cx)
+        else:
+            assert a3 is None and pw.K == 9 * pw.cin, (pw.K, pw.cin)
     else:
         M = a.shape[0]
         p.lda = a.stride(0)
         p.c1 = a.shape[1]
+        assert a3 is None
         if a2 is not None:
             assert a2.dtype == BF16 and a2.stride(-1) == 1
             p.a2 = _ptr(a2)

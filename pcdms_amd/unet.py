@@ -40,6 +40,10 @@ TIME_TABLE = os.environ.get("PCDM_TIME_TABLE", "1") != "0"               # A/B s
 # rounded to bf16 like any weight: the same 2 M C 5C FLOPs, one launch instead of two, and the block's last residual state (h3: M x C bf16)
 # is neither written nor read back.  PCDM_FUSE_FF_OUT=0: the two launches (A/B switch, tools/README.md).
 FUSE_FF_OUT = os.environ.get("PCDM_FUSE_FF_OUT", "1") != "0"
+# ResnetBlock2D: conv2(h) + conv_shortcut(x) as ONE contraction (round 6).  The 1x1 shortcut over the block's input is K-concatenated behind
+# conv2's nine taps (ops.pack_conv3x3_shortcut; pcdm_gemm_params.a3, ABI 5): the 14 shortcut launches of a step and the read-back of their
+# outputs as conv2's residual disappear.  PCDM_FUSE_SHORTCUT=0: the two launches (A/B switch, tools/README.md).
+FUSE_SHORTCUT = os.environ.get("PCDM_FUSE_SHORTCUT", "1") != "0"
 
 _DEFAULT_CONFIG: Dict[str, Any] = dict(
     sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
@@ -345,6 +349,9 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             r["conv1"], r["conv2"] = conv(p + "conv1."), conv(p + "conv2.")
             if cin != cout:
                 r["short"] = lin(p + "conv_shortcut.")
+                if FUSE_SHORTCUT:
+                    r["conv2s"] = ops.pack_conv3x3_shortcut(sd[p + "conv2.weight"], sd[p + "conv2.bias"], sd[p + "conv_shortcut.weight"],
+                                                            sd[p + "conv_shortcut.bias"], dev)
             tw.append(sd[p + "time_emb_proj.weight"])
             tb.append(sd[p + "time_emb_proj.bias"])
             off += cout
@@ -658,6 +665,9 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                 h1 = ops.gemm(n1, r["conv1"], self._buf("c1", (M, cout)), conv=cv, rowvec=tv, rows_per_batch=HW_, defer_reduce=False,
                               rowvec_step=rv_step, rowvec_step_stride=rv_stride, rowvec_step_count=rv_count, step_error=rv_err)
             n2 = ops.groupnorm(h1, None, B, HW_, G, eps, r["n2"][0], r["n2"][1], True, self._buf("gn", (M, cout)), ws)
+            if "conv2s" in r:   # conv2 + conv_shortcut as one contraction: the block's input enters through the extra K (FUSE_SHORTCUT above)
+                return ops.gemm(n2, r["conv2s"], self._buf(name, (M, cout)), conv=cv, a2=x1, a3=x2, defer_reduce=True if gn_next else None,
+                                rows_per_batch=HW_)
             if "short" in r:
                 res = ops.gemm(x1, r["short"], self._buf("sc", (M, cout)), a2=x2)
             else:

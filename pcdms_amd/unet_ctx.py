@@ -88,6 +88,8 @@ class UNetContext:
             self._set_w(p + "conv2", r["conv2"])
             if "short" in r:
                 self._set_w(p + "conv_shortcut", r["short"])
+            if "conv2s" in r:
+                self._set_w(p + "conv2s", r["conv2s"])
             self._set_v(p + "norm1", r["n1"])
             self._set_v(p + "norm2", r["n2"])
         for p, _, _ in _transformers(u):

@@ -52,7 +52,7 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_struct_layouts_match_the_header(tmp_path):
     """The ctypes mirrors in pcdms_amd/_lib.py against the C structs of include/pcdm.h as gcc lays them out: size and the offset of every
     field (pcdm_gemm_params grew without a version bump -- an ABI drift between the header and a binding must fail a test, and
-    ``pcdm_version()`` must say 4 for the struct that starts with ``struct_size`` and ends with ``step_error``)."""
+    ``pcdm_version()`` must say 5 for the struct that starts with ``struct_size`` and ends with ``a3``, ``lda3``)."""
     import shutil
     import subprocess
 
@@ -82,7 +82,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct pcdm_gemm_params {"):hdr.index("} pcdm_gemm_params;")], flags=re.S)
     names = re.findall(r"(\w+)\s*(?:,|;)", body.split("{", 1)[1])
     assert names == [f for f, _ in _lib.GemmParams._fields_], (names, [f for f, _ in _lib.GemmParams._fields_])
-    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 4
+    assert ctypes.CDLL(str(build_lib())).pcdm_version() == 5
 
 
 def test_gemm_params_of_another_size_are_refused(monkeypatch):

@@ -440,6 +440,57 @@ def test_conv3x3(backend, mode):
     close(out.view(B, Ho, Wo, Cout), ref.permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("case", ["one_source", "two_sources", "split_k", "tiles"])
+def test_conv3x3_with_shortcut_k(backend, case):
+    """ResnetBlock2D's ``conv2(h) + conv_shortcut(x)`` as ONE contraction (pcdm_gemm_params.a3, ABI 5; ops.pack_conv3x3_shortcut): the 1x1
+    shortcut over the block's input -- one tensor, or the two halves [x | skip] of the up path's concat, as row-strided views -- is
+    K-concatenated behind the nine taps.  Against F.conv2d of both layers in fp32; ``tiles``: every full-size tile family the UNet's
+    conv2 launches use gives the same answer to rounding; ``split_k``: the extra K-tiles may fall into any K slice."""
+    dev = backend.device
+    if backend.is_emu:
+        B, H, W, C, C1, C2 = 2, 6, 5, 64, 128, 64
+    else:
+        B, H, W, C, C1, C2 = (8, 64, 88, 320, 320, 320) if case != "split_k" else (8, 16, 22, 1280, 1280, 640)
+    if case == "one_source":
+        C2 = 0
+    M = B * H * W
+    h = rnd(B, C, H, W, seed=250)
+    w = rnd(C, C, 3, 3, seed=251, scale=1 / math.sqrt(9 * C))
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(252))
+    xcat = rnd(M, C1 + C2, seed=253)
+    wsc = rnd(C, C1 + C2, 1, 1, seed=254, scale=1 / math.sqrt(C1 + C2))
+    bsc = torch.randn(C, generator=torch.Generator().manual_seed(255))
+    pw = ops.pack_conv3x3_shortcut(w.float(), bias, wsc.float(), bsc, dev)
+    assert pw.K == 9 * C + C1 + C2 and pw.cin == C
+    ref = F.conv2d(h.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(M, C) + xcat.float() @ wsc.float().reshape(C, -1).t() + bsc
+    hh = h.permute(0, 2, 3, 1).contiguous().to(dev)
+    # the sources as column windows of wider buffers (row stride != width), like the skip tensors of the UNet
+    wide = torch.zeros(M, C1 + C2 + 64, dtype=BF16)
+    wide[:, :C1 + C2] = xcat
+    wide = wide.to(dev)
+    a2 = wide[:, :C1]
+    a3 = wide[:, C1:C1 + C2] if C2 else None
+    cv = dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W)
+    if case == "tiles":
+        tiles = [(2, 1), (4, 1)] if backend.is_emu else [(22, 1), (21, 1), (11, 1), (4, 1), (1, 1), (17, 1)]
+    elif case == "split_k":
+        tiles = [(2, 3)] if backend.is_emu else [(21, 4), (4, 8), (23, 12)]
+    else:
+        tiles = [(0, 1)]
+    for tile, sk in tiles:
+        if tile and pw.Npad % ops.TILE_SHAPES[tile][1]:
+            continue
+        out = torch.empty(M, C, dtype=BF16, device=dev)
+        ops.gemm(hh, pw, out, conv=cv, a2=a2, a3=a3, tile=tile, split_k=sk)
+        backend.sync()
+        close(out, ref)
+    # refusals (pcdm.h: -1): extra K without its source, a source on a plain convolution, stride 2
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm(hh, pw, torch.empty(M, C, dtype=BF16, device=dev), conv=cv)
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm(hh, ops.pack_conv3x3(w.float(), bias, dev), torch.empty(M, C, dtype=BF16, device=dev), conv=cv, a2=a2)
+
+
 def test_conv_in_padded_channels(backend):
     """conv_in: 9 input channels zero-padded to 64 (weights too) == the 9-channel conv."""
     dev = backend.device

@@ -154,6 +154,45 @@ def test_ff_out_fusion_matches_the_two_launches(backend, monkeypatch):
     assert ((outs[True] - outs[False]).norm() / outs[False].norm()).item() < 1e-2
 
 
+def test_shortcut_fusion_matches_the_two_launches(backend, monkeypatch):
+    """``conv2(h) + conv_shortcut(x)`` of every channel-changing ResnetBlock2D as one contraction (pcdms_amd/unet.py FUSE_SHORTCUT; resnet.py's
+    forward as composed at stage2_inpaint_unet_2d_condition.py:321-344,407-430): a model packed with it launches one GEMM fewer per such
+    block, both forms stay inside the forward tolerance against the fp32 oracle, and they agree with each other to bf16 rounding of the
+    residual the fused form no longer rounds."""
+    from pcdms_amd import ops, unet as U
+    cfg = UNetConfig.tiny()
+    B, h, w, L = (2, 8, 8, 5) if backend.is_emu else (4, 16, 24, 10)
+    sd = synth_state_dict(cfg, seed=0, random_affine=True)
+    s, e, c, p = _inputs(cfg, B, h, w, L)
+    dev = backend.device
+    outs, launches = {}, {}
+    for fused in (True, False):
+        monkeypatch.setattr(U, "FUSE_SHORTCUT", fused)
+        m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+        m.load_state_dict(sd)
+        m.to(dev)
+        m._pack()
+        blocks = [r for r in m._w.values() if isinstance(r, dict) and "short" in r]
+        assert blocks and all(("conv2s" in r) == fused for r in blocks)
+        count = {"n": 0}
+        orig_gemm = ops.gemm
+
+        def counting(*args, **kw):
+            count["n"] += 1
+            return orig_gemm(*args, **kw)
+        monkeypatch.setattr(ops, "gemm", counting)
+        out = m(s.to(dev), torch.tensor(981, device=dev), e.to(dev), class_labels=c.to(dev), my_pose_cond=p.to(dev), return_dict=False)[0]
+        backend.sync()
+        monkeypatch.setattr(ops, "gemm", orig_gemm)
+        outs[fused], launches[fused] = out.float().cpu(), count["n"]
+    assert launches[False] - launches[True] == len(blocks), (launches, len(blocks))
+    ref = unet_forward(sd, cfg, s, torch.tensor(981), e, c, p)
+    rel_f, _ = _check(outs[True], ref)
+    rel_u, _ = _check(outs[False], ref)
+    assert rel_f <= rel_u * 1.25 + 1e-4, (rel_f, rel_u)
+    assert ((outs[True] - outs[False]).norm() / outs[False].norm()).item() < 1e-2
+
+
 @pytest.mark.gpu
 def test_unet_latent_not_divisible_by_8(gpu_backend):
     """Latent 20x11 (like the stage-3 latent 64x44 of a 352-wide image): the stride-2 convs round up (11 -> 6 -> 3 -> 2) and
