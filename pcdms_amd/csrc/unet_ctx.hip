@@ -719,7 +719,8 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
     };
     auto resnet = [&](const std::string& p, const void* x1, int C1, const void* x2, int C2, int HW_, int hh, int ww, const std::string& out_name,
                       bool gn_next, bool shared_in = false) -> void* {   // gn_next: the next reader of the block's output is a GroupNorm (split-K reduce folded into it)
-        const PW *cv1 = R.pw(p + "conv1"), *cv2 = R.pw(p + "conv2");
+        const bool composed = u->w.count(p + "conv2s") != 0;   // conv2 + conv_shortcut registered as one set of rows (then neither need be registered)
+        const PW *cv1 = R.pw(p + "conv1"), *cv2 = composed ? nullptr : R.pw(p + "conv2");
         if (R.rc) return nullptr;
         const int cin = C1 + C2, cout = cv1->N, M = B * HW_;
         Run::G g;
@@ -738,7 +739,7 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
             R.gemm(R.buf("gn"), cin, M, cv1, R.buf("c1"), g);
         }
         R.groupnorm(R.buf("c1"), cout, nullptr, 0, B, HW_, eps, R.vec(p + "norm2.weight"), R.vec(p + "norm2.bias"), 1, R.buf("gn"));
-        if (u->w.count(p + "conv2s")) {
+        if (composed) {
             // conv2 + conv_shortcut as ONE contraction (weight rows [9 cout taps | C1 | C2], composed by the host: pcdms_amd/unet.py FUSE_SHORTCUT;
             // registered as "<resnet>conv2s"): the block's input enters through the extra K, no shortcut launch, no residual
             Run::G g2;

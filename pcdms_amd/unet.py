@@ -346,12 +346,14 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             r: Dict[str, Any] = dict(cin=cin, cout=cout, toff=off)
             r["n1"] = (f32(p + "norm1.weight"), f32(p + "norm1.bias"))
             r["n2"] = (f32(p + "norm2.weight"), f32(p + "norm2.bias"))
-            r["conv1"], r["conv2"] = conv(p + "conv1."), conv(p + "conv2.")
-            if cin != cout:
-                r["short"] = lin(p + "conv_shortcut.")
-                if FUSE_SHORTCUT:
-                    r["conv2s"] = ops.pack_conv3x3_shortcut(sd[p + "conv2.weight"], sd[p + "conv2.bias"], sd[p + "conv_shortcut.weight"],
-                                                            sd[p + "conv_shortcut.bias"], dev)
+            r["conv1"] = conv(p + "conv1.")
+            if cin != cout and FUSE_SHORTCUT:   # (the composed rows replace both layers: neither is packed a second time)
+                r["conv2s"] = ops.pack_conv3x3_shortcut(sd[p + "conv2.weight"], sd[p + "conv2.bias"], sd[p + "conv_shortcut.weight"],
+                                                        sd[p + "conv_shortcut.bias"], dev)
+            else:
+                r["conv2"] = conv(p + "conv2.")
+                if cin != cout:
+                    r["short"] = lin(p + "conv_shortcut.")
             tw.append(sd[p + "time_emb_proj.weight"])
             tb.append(sd[p + "time_emb_proj.bias"])
             off += cout
@@ -363,7 +365,7 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         for p, c, h in _transformers(self):
             a: Dict[str, Any] = dict(c=c, heads=h)
             a["norm"] = (f32(p + "norm.weight"), f32(p + "norm.bias"))
-            a["proj_in"], a["proj_out"] = lin(p + "proj_in."), lin(p + "proj_out.")
+            a["proj_in"] = lin(p + "proj_in.")
             b = p + "transformer_blocks.0."
             for i in (1, 2, 3):
                 a[f"ln{i}"] = (f32(b + f"norm{i}.weight"), f32(b + f"norm{i}.bias"))
@@ -374,11 +376,12 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
             a["kv2"] = ops.pack_linear(torch.cat([sd[b + "attn2.to_k.weight"], sd[b + "attn2.to_v.weight"]], 0), None, dev)
             a["o2"] = lin(b + "attn2.to_out.0.")
             a["ff1"] = ops.pack_geglu(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"], dev)
-            a["ff2"] = lin(b + "ff.net.2.")
-            if FUSE_FF_OUT:
+            if FUSE_FF_OUT:   # (the composed weight replaces both layers: neither is packed a second time)
                 w2, b2 = sd[b + "ff.net.2.weight"].double(), sd[b + "ff.net.2.bias"].double()
                 wp, bp = sd[p + "proj_out.weight"].double().reshape(c, c), sd[p + "proj_out.bias"].double()
                 a["ffo"] = ops.pack_linear(torch.cat([wp @ w2, wp], 1).float(), (wp @ b2 + bp).float(), dev)
+            else:
+                a["ff2"], a["proj_out"] = lin(b + "ff.net.2."), lin(p + "proj_out.")
             if True:   # second copies of the three LayerNorm-fed linears with the LayerNorm FOLDED into the weights: K = 320 -> the
                        # A-in-registers kernel (rowgemm.hip); K = 640 / 1280 (round 5) -> the LNF instances of the tiled kernel (gemm.hip)
                 ln = [(sd[b + f"norm{i}.weight"], sd[b + f"norm{i}.bias"]) for i in (1, 2, 3)]

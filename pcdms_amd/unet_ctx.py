@@ -85,7 +85,8 @@ class UNetContext:
         for p, _, _, _ in _resnets(u):
             r = W[p]
             self._set_w(p + "conv1", r["conv1"])
-            self._set_w(p + "conv2", r["conv2"])
+            if "conv2" in r:
+                self._set_w(p + "conv2", r["conv2"])
             if "short" in r:
                 self._set_w(p + "conv_shortcut", r["short"])
             if "conv2s" in r:

@@ -123,8 +123,8 @@ def test_ff_out_fusion_matches_the_two_launches(backend, monkeypatch):
         m.load_state_dict(sd)
         m.to(dev)
         m._pack()
-        blocks = [a for a in m._w.values() if isinstance(a, dict) and "ff2" in a]
-        assert blocks and all(("ffo" in a) == fused for a in blocks)
+        blocks = [a for a in m._w.values() if isinstance(a, dict) and "ff1" in a]
+        assert blocks and all(("ffo" in a) == fused and ("ff2" in a) != fused and ("proj_out" in a) != fused for a in blocks)
         if fused:   # [Wp W2 | Wp], bias Wp b2 + bp -- to bf16 rounding of the packed copy
             a = blocks[0]
             pre = next(k for k, v in m._w.items() if v is a)
@@ -172,8 +172,8 @@ def test_shortcut_fusion_matches_the_two_launches(backend, monkeypatch):
         m.load_state_dict(sd)
         m.to(dev)
         m._pack()
-        blocks = [r for r in m._w.values() if isinstance(r, dict) and "short" in r]
-        assert blocks and all(("conv2s" in r) == fused for r in blocks)
+        blocks = [r for r in m._w.values() if isinstance(r, dict) and "conv1" in r and r["cin"] != r["cout"]]
+        assert blocks and all(("conv2s" in r) == fused and ("conv2" in r) != fused and ("short" in r) != fused for r in blocks)
         count = {"n": 0}
         orig_gemm = ops.gemm
 
