@@ -478,8 +478,11 @@ extern "C" int pcdm_flash_attn_fp8(const void* q, int64_t ldq, const void* k8, i
     return 0;
 }
 
-// A/B switch of the row-sum path (tools/bench_attn.py; PCDM_ATTN_ROWSUM=valu|mfma in the environment at load time)
-static bool g_rowsum_valu = [] { const char* e = getenv("PCDM_ATTN_ROWSUM"); return e && e[0] == 'v'; }();
+// The row-sum path (PCDM_ATTN_ROWSUM=valu|mfma in the environment at load time; tools/bench_attn.py).  Default since round 6: VALU -- per launch, back
+// to back, the two were within 1 % of each other in every earlier round; IN the denoise step the VALU form is +0.5 % end to end in three interleaved
+// same-box pairs (6.122 / 6.122 / 6.125 -> 6.160 / 6.147 / 6.150 images/s, profiles/r6_ab_attn_rowsum.json): four MFMAs fewer per key tile on a
+// matrix pipe that the chip's power budget, not its issue rate, holds back in the step.
+static bool g_rowsum_valu = [] { const char* e = getenv("PCDM_ATTN_ROWSUM"); return !(e && e[0] == 'm'); }();
 // extra dynamic LDS per workgroup: an occupancy knob for experiments (e.g. 50000 -> 2 workgroups per CU instead of 3)
 static int g_lds_pad = [] { const char* e = getenv("PCDM_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
 
