@@ -55,6 +55,19 @@ def test_c_schedule_equals_python_schedule_stage2(backend):
         assert rel <= 2.5e-2, rel
 
 
+def test_c_schedule_without_the_composed_weights(backend, monkeypatch):
+    """A host that registers the plain layers only (no ``<resnet>conv2s``, no ``<transformer>ffo``: pcdm.h lists both as optional) gets the
+    two-launch forms of ``conv2 + conv_shortcut`` and ``ff.net.2 -> proj_out`` from ``pcdm_unet_forward`` -- still bit for bit the Python
+    schedule of a model packed the same way (pcdms_amd/unet.py FUSE_SHORTCUT / FUSE_FF_OUT off)."""
+    from pcdms_amd import unet as U
+    monkeypatch.setattr(U, "FUSE_SHORTCUT", False)
+    monkeypatch.setattr(U, "FUSE_FF_OUT", False)
+    cfg = UNetConfig.tiny()
+    B, h, w, L, n0 = (2, 8, 8, 5, 1) if backend.is_emu else (4, 16, 24, 9, 2)
+    _, _, ref, out = _run_both(backend, cfg, B, h, w, L, n0)
+    assert torch.equal(out, ref), (out - ref).abs().max()
+
+
 def test_c_schedule_fp8_attention(backend):
     """``pcdm_unet_set_attention_fp8``: the C schedule with every attention on e4m3 operands (BASELINE.json configs[4]) -- K / V^T quantised
     per attention and, for the context, once per conditioning -- equals the Python schedule's fp8 path bit for bit (VERDICT r3 weak #10)."""
