@@ -17,7 +17,11 @@ from pcdms_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 BF = torch.bfloat16
-lib = C.CDLL(str(ROOT / "tools" / "ubench" / "libprefetch_probe.so"))
+_so = ROOT / "tools" / "ubench" / "libprefetch_probe.so"
+if not _so.exists():   # (built on first use: hipcc cross-compiles without a GPU, the .so travels with gpurun's snapshot)
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", str(_so.with_name("prefetch_probe.hip")), "-o", str(_so)])
+lib = C.CDLL(str(_so))
 lib.prefetch_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
 sink = torch.zeros(4, dtype=torch.int32, device=dev)
 flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
