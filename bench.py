@@ -217,7 +217,10 @@ def main():
                    "flops_note": "e2e_tflops_per_gpu and roofline.e2e_frac credit the UN-HOISTED algorithmic FLOPs of SURVEY.md §8d "
                                  "(118.84 TFLOP per image); executed FLOPs are ~3.5% lower: the cross-attention K/V projections run once "
                                  "per call instead of once per step, and the all-zero-context CFG half of every cross-attention "
-                                 "(LN2, to_q, QK^T/PV, to_out contraction) is skipped (output == to_out.bias exactly)"},
+                                 "(LN2, to_q, QK^T/PV, to_out contraction) is skipped (output == to_out.bias exactly); round 6: the three "
+                                 "Upsample2D convolutions run as their phase decomposition (2x2 convolutions of the low-res tensor with summed taps: "
+                                 "4/9 of their 2*M*N*9C FLOPs, another ~4.5% of the step) -- roofline.executed_gflop_per_denoise_step and "
+                                 "e2e_frac_executed count what is issued"},
     }
     N8 = args.configs2_batch
     if world == args.configs2_world and world > 1 and N != N8 and not args.no_configs2:

@@ -165,8 +165,16 @@ typedef struct pcdm_gemm_params {
                                    no shortcut launch, no residual round trip.  stride 1, no upsample, Hi == Ho, Wi == Wo, symmetric padding, no dup_rows;
                                    c1, cx multiples of 64; lda2 >= c1, lda3 >= cx - c1, both multiples of 8; else -1 */
     int64_t lda3;
+    uint64_t tap_lut;           /* conv3x3 over a SUBSET of the nine taps per output-channel group (ABI 5): with tap_group_n > 0 the K axis holds ntaps = K / cin
+                                   (1..4) taps; output channels [g tap_group_n, (g + 1) tap_group_n) (g < 4) use the taps whose ids (ky * 3 + kx, 0..8) are the
+                                   nibbles of bits [16 g, 16 g + 4 ntaps) of tap_lut, in K order; W rows are [ntaps taps x cin].  The phase decomposition of
+                                   Upsample2D: conv3x3(nearest-upsample x2 (x)) at output pixel (2y + a, 2x + b) is a 2x2 convolution of x with summed taps, i.e.
+                                   one 3x3 launch on the LOW-RES input with N = 4 Cout (group = phase 2a + b, taps {3(a+i) + b + j}), 4/9 of the FLOPs, followed by
+                                   pcdm_pixel_shuffle2 (diffusers Upsample2D as composed at stage2_inpaint_unet_2d_condition.py:407-430).  stride 1, no upsample,
+                                   no extra K (a2 / a3), tap_group_n a multiple of the N tile in use (else -1: pick a tile that divides it) */
+    int32_t tap_group_n;
 } pcdm_gemm_params;
-/* pcdm_version() == 5: the struct above STARTS with struct_size and ends with a3, lda3 (4: ended with rowvec_step_count, step_error; 3: no struct_size, ended with
+/* pcdm_version() == 5: the struct above STARTS with struct_size and ends with a3, lda3, tap_lut, tap_group_n (4: ended with rowvec_step_count, step_error; 3: no struct_size, ended with
  * ln_row_stats, row_stats_out, gn_stats_out, gn_stats_gs -- the last two are gone with the GroupNorm-statistics producer; 2: ended with
  * dup_rows; 1: with ln_eps).  Zero-initialise it (memset), set struct_size = sizeof(pcdm_gemm_params): the library compares it with its own and
  * returns -1 on a mismatch, so a host built against another header fails at its first call instead of having trailing fields misread.
@@ -271,6 +279,9 @@ int pcdm_image_to_uint8(const float* x, void* out, int B, int cstride, int HW, p
 int pcdm_lincomb(float* y, int nin, const float* const* xs, const float* c, int64_t n, pcdm_stream_t s);
 /* *step_dev += 1 */
 int pcdm_advance_step(int32_t* step_dev, pcdm_stream_t s);
+/* out NHWC bf16 [B, 2H, 2W, C] <- in [B * H * W, 4 * C] bf16 (columns = phase 2a + b major, then channel): out[b, 2y + a, 2x + bb, c] =
+ * in[(b, y, x), (2a + bb) C + c].  The second half of the phase-decomposed Upsample2D convolution (pcdm_gemm_params.tap_lut).  C % 8 == 0. */
+int pcdm_pixel_shuffle2(const void* in, void* out, int B, int H, int W, int C, pcdm_stream_t s);
 
 /* ---- The UNet forward as ONE entry ("a fused unet_forward(ctx, ...)" over an opaque context).
  * Replaces Stage2_InapintUNet2DConditionModel.forward (/root/reference/src/models/stage2_inpaint_unet_2d_condition.py:579-825) for a host

@@ -44,7 +44,7 @@ class GemmParams(C.Structure):
         ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("defer_reduce", C.c_int32),
         ("rowvec_step", C.c_void_p), ("rowvec_step_stride", C.c_int64), ("dup_rows", C.c_int32),
         ("ln_row_stats", C.c_void_p), ("row_stats_out", C.c_void_p), ("rowvec_step_count", C.c_int32), ("step_error", C.c_void_p),
-        ("a3", C.c_void_p), ("lda3", C.c_int64),
+        ("a3", C.c_void_p), ("lda3", C.c_int64), ("tap_lut", C.c_uint64), ("tap_group_n", C.c_int32),
     ]
 
     def __init__(self, *args, **kw):
@@ -102,6 +102,7 @@ _SIGS = {
     "pcdm_gaussian_sample": ([_P, _P, _P, _I, _I, _I, _F, _P], C.c_int),
     "pcdm_image_to_uint8": ([_P, _P, _I, _I, _I, _P], C.c_int),
     "pcdm_advance_step": ([_P, _P], C.c_int),
+    "pcdm_pixel_shuffle2": ([_P, _P, _I, _I, _I, _I, _P], C.c_int),
     "pcdm_unet_create": ([C.POINTER(UNetConfig)], _P),
     "pcdm_unet_destroy": ([_P], None),
     "pcdm_unet_last_error": ([_P], C.c_char_p),

@@ -122,6 +122,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
     a.a3 = (const u16*)p->a3;
     a.lda3 = p->lda3;
     a.xinv = 0;
+    a.tap_lut = 0;
+    a.tap_group_n = 0;
     a.B = p->B; a.Hi = p->Hi; a.Wi = p->Wi; a.Ho = p->Ho; a.Wo = p->Wo;
     a.stride = p->stride; a.upsample = p->upsample; a.cin = p->cin;
     a.pad = p->no_pad_lo ? 0 : 1;
@@ -170,7 +172,19 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         if (p->epilogue != PCDM_EPI_STORE || !p->ws || a.split_k > p->K / BK || a.split_k > 64) return -1;
         if (p->ws_floats < (int64_t)a.split_k * p->M * p->Npad) return -1;
     }
-    if (p->conv) {
+    if (p->conv && p->tap_group_n > 0) {
+        // a subset of the nine taps per output-channel group (pcdm_gemm_params.tap_lut): K = ntaps cin
+        const int ntaps = p->cin > 0 ? p->K / p->cin : 0;
+        if (p->cin <= 0 || p->cin % BK || p->K != ntaps * p->cin || ntaps < 1 || ntaps > 4 || p->stride != 1 || p->upsample || p->no_pad_lo || p->dup_rows ||
+            p->a2 || p->a3 || p->Hi != p->Ho || p->Wi != p->Wo || p->N % p->tap_group_n || p->N / p->tap_group_n > 4 || p->tap_group_n % 64)
+            return -1;
+        for (int g = 0; g < p->N / p->tap_group_n; ++g)
+            for (int t = 0; t < ntaps; ++t)
+                if (((p->tap_lut >> (16 * g + 4 * t)) & 15) > 8 || ((p->tap_lut >> (16 * g)) & 0xffff) == 0) return -1;
+        if (p->M != p->B * p->Ho * p->Wo) return -1;
+        a.tap_lut = p->tap_lut;
+        a.tap_group_n = p->tap_group_n;
+    } else if (p->conv) {
         const int cx = p->K - 9 * p->cin;   // extra K behind the nine taps: a 1x1 convolution over a2 [+ a3] at the output pixel (pcdm_gemm_params.a3)
         if (p->cin <= 0 || p->cin % BK || cx < 0 || (p->stride != 1 && p->stride != 2)) return -1;
         if (cx == 0 ? (p->a2 || p->a3)

@@ -12,6 +12,8 @@ struct GemmArgs {
     int c1;
     const u16* a3;     // conv with extra K (K = 9 cin + cx): the 1x1 sources behind the taps are a2 (c1 channels) and a3 (cx - c1); pcdm_gemm_params.a3
     int64_t lda3;
+    uint64_t tap_lut;  // conv over a SUBSET of the nine taps per output-channel group (pcdm_gemm_params.tap_lut / tap_group_n): 4 groups x 4 nibbles of true tap ids
+    int tap_group_n;   // output channels per group (a multiple of the N tile in use); 0: the plain nine taps
     uint32_t xinv;     // ceil(2^31 / (cin / 64)): pixel index of a conv row from its centre-tap offset (gemm_kernel.inc issue_tile)
     int B, Hi, Wi, Ho, Wo, stride, upsample, cin;
     int pad;   // conv: 1 = symmetric zero padding 1 (default); 0 = bottom/right only (VAE encoder Downsample2D)

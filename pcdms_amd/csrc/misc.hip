@@ -345,6 +345,22 @@ __global__ void image_to_uint8_kernel(const float* __restrict__ x, uint8_t* __re
     }
 }
 
+// out NHWC [B, 2H, 2W, C] <- in [B H W, 4 C] (phase 2a + b major): the pixel shuffle behind the phase-decomposed Upsample2D convolution.
+// One thread per 16 bytes of output: consecutive threads walk the channels of one output pixel, then the next pixel of the output row.
+__global__ void pixel_shuffle2_kernel(const u16* __restrict__ in, u16* __restrict__ out, int H, int W, int C8, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % C8);
+    const int64_t px = i / C8;                  // output pixel index (b, Y, X)
+    const int W2 = 2 * W;
+    const int X = (int)(px % W2);
+    const int64_t bY = px / W2;                 // b * 2H + Y
+    const int Y = (int)(bY % (2 * H));
+    const int64_t b = bY / (2 * H);
+    const int64_t src = (((b * H + (Y >> 1)) * W + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * C8 + c8;
+    ((u32x4*)out)[i] = ((const u32x4*)in)[src];
+}
+
 __global__ void advance_step_kernel(int32_t* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
 }
@@ -539,6 +555,14 @@ extern "C" int pcdm_image_to_uint8(const float* x, void* out, int B, int cstride
     if (!x || !out || B <= 0 || cstride < 3 || HW <= 0) return -1;
     const int64_t total = (int64_t)B * HW;
     PCDM_LAUNCH(image_to_uint8_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, x, (uint8_t*)out, cstride, HW, total);
+    PCDM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pcdm_pixel_shuffle2(const void* in, void* out, int B, int H, int W, int C, pcdm_stream_t s) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (((uintptr_t)in | (uintptr_t)out) & 15)) return -1;
+    const int64_t total = (int64_t)B * 2 * H * 2 * W * (C / 8);
+    PCDM_LAUNCH(pixel_shuffle2_kernel, grid1d(total, 256), dim3(256), 0, (hipStream_t)s, (const u16*)in, (u16*)out, H, W, C / 8, total);
     PCDM_CHECK_LAUNCH();
     return 0;
 }

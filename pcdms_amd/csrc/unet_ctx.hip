@@ -181,6 +181,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         int64_t ldo2 = 0;
         int vt_col0 = 0;
         int conv = 0, B = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, stride = 1, upsample = 0;
+        uint64_t tap_lut = 0;      // conv over a subset of the nine taps per output-channel group (pcdm_gemm_params.tap_lut / tap_group_n)
+        int tap_group_n = 0;
         int zero_rows = 0;
         int64_t ldo = 0;   // 0: N (GEGLU / NCHW: N)
         const PW* ln = nullptr;   // LayerNorm-folded twin of the weight (rowgemm tiles, or the tiled kernel with in-kernel statistics / producer partials)
@@ -211,6 +213,8 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.lda2 = g.lda2;
         p.a3 = g.a3;
         p.lda3 = g.lda3;
+        p.tap_lut = g.tap_lut;
+        p.tap_group_n = g.tap_group_n;
         p.conv = g.conv;
         if (g.conv) {
             p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi; p.Ho = g.Ho; p.Wo = g.Wo;
@@ -237,7 +241,7 @@ struct Run {   // one forward / conditioning pass: helpers around the C-ABI call
         p.rowvec_step_stride = g.rowvec_step_stride;
         p.rowvec_step_count = g.rowvec_step_count;
         p.step_error = g.step_error;
-        const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : (g.dup_rows ? 2 : 0)};
+        const TileKey key{0, M, w->Npad, w->K, g.conv, g.conv ? g.stride + (g.tap_group_n ? 20 : 0) : 0, g.upsample, g.epilogue, g.a2 ? 1 : 0, g.residual ? 1 : 0, g.zero_rows ? 1 : (g.dup_rows ? 2 : 0)};
         auto it = u->tiles.find(key);
         // (a table entry that names the A-in-registers kernel for a call it cannot serve -- row vector, fewer residual rows than M -- is skipped:
         //  the key does not carry those; pcdms_amd.ops.gemm does the same)
@@ -917,6 +921,19 @@ extern "C" int pcdm_unet_forward(pcdm_unet* u, const void* x_in, const int64_t* 
         }
         if (i != n - 1) {
             const int ho = skips.back().hh, wo = skips.back().ww;   // = (2 hh, 2 ww) unless a down conv rounded an odd size up
+            const std::string up4 = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv4";
+            if (u->w.count(up4) && ho == 2 * hh && wo == 2 * ww) {
+                // the phase decomposition of conv3x3(nearest x2 (x)) (registered as "...upsamplers.0.conv4": pcdms_amd/ops.py pack_upsample_phases):
+                // one 3x3 launch on the low-res tensor with N = 4 C, every output-channel group (= output phase) over its four taps, then the shuffle
+                Run::G g4;
+                g4.conv = 1; g4.B = B; g4.Hi = hh; g4.Wi = ww; g4.Ho = hh; g4.Wo = ww;
+                g4.tap_lut = 0x8754764354214310ull; g4.tap_group_n = cx;
+                R.gemm(x, 0, B * hh * ww, R.pw(up4), R.buf("c1"), g4);
+                R.chk(pcdm_pixel_shuffle2(R.buf("c1"), R.buf("us"), B, hh, ww, cx, s), "pcdm_pixel_shuffle2");
+                x = R.buf("us");
+                hh = ho; ww = wo;
+                continue;
+            }
             Run::G g;
             g.conv = 1; g.B = B; g.Hi = hh; g.Wi = ww; g.Ho = ho; g.Wo = wo; g.upsample = 1;
             g.defer = 1;   // -> the next block's norm1

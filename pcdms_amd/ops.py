@@ -158,6 +158,7 @@ class PackedWeight:
     cin: int = 0       # conv: (padded) input channels
     geglu: bool = False
     alg_nk: int = 0    # algorithmic N*K (un-padded; GEGLU counts both halves) for FLOP accounting
+    exec_nk: int = 0   # N*K the launch really contracts when that is LESS than the algorithmic figure (the phase-decomposed upsample convolution); 0: = alg_nk
     wsum: Optional[torch.Tensor] = None   # fp32 [Npad]: row sums of the packed bf16 weights when they carry a folded LayerNorm
 
 
@@ -206,6 +207,41 @@ def pack_conv3x3_shortcut(w: torch.Tensor, bias: Optional[torch.Tensor], w_sc: t
     pw.cin = Cp
     pw.alg_nk = N * (9 * Cin + ws.shape[1])
     return pw
+
+
+UPSAMPLE_TAP_LUT = sum(((3 * (a + i) + b + j) << (16 * (2 * a + b) + 4 * (2 * i + j))) for a in (0, 1) for b in (0, 1) for i in (0, 1) for j in (0, 1))
+
+
+def pack_upsample_phases(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> PackedWeight:
+    """Upsample2D's ``conv3x3(nearest x2 (x))`` [N, C, 3, 3] as FOUR 2x2 convolutions of the low-res input, one per output phase (a, b) =
+    (row parity, column parity): output pixel (2y + a, 2x + b) reads low-res rows {y - 1 + a, y + a} and columns {x - 1 + b, x + b}; the taps
+    of the 3x3 kernel that land on the same low-res pixel are SUMMED (fp64, then bf16 like any weight).  Rows [phase 2a + b][N], K = [4 taps][C]
+    with the tap order (i, j) of ``UPSAMPLE_TAP_LUT``: one launch with ``tap_group_n = N`` on the low-res tensor, 4/9 of the FLOPs of the
+    convolution on the upsampled one, then ``pixel_shuffle2``.  Exact algebra; zero padding agrees (the upsampled border row -1 is low-res row -1)."""
+    N, Cin = w.shape[:2]
+    assert Cin % 64 == 0 and N % 64 == 0, (N, Cin)
+    w = w.double()
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}      # phase parity -> (taps summed into window position 0, position 1)
+    blocks = []
+    for a in (0, 1):
+        for b in (0, 1):
+            k = torch.zeros(N, 2, 2, Cin, dtype=torch.float64)
+            for i in (0, 1):
+                for j in (0, 1):
+                    k[:, i, j] = sum(w[:, :, ky, kx] for ky in rows[a][i] for kx in rows[b][j])
+            blocks.append(k.reshape(N, 4 * Cin))
+    pw = pack_linear(torch.cat(blocks, 0).float(), None if bias is None else bias.float().repeat(4), device)
+    pw.cin = Cin
+    pw.alg_nk = N * 9 * Cin * 4    # algorithmic FLOPs stay those of the 3x3 convolution on the upsampled tensor (SURVEY.md §8d): 2 (4 M) N 9 C
+    pw.exec_nk = 4 * N * 4 * Cin   # ... what the launch executes: 4/9 of them
+    return pw
+
+
+def pixel_shuffle2(x: torch.Tensor, out: torch.Tensor, B: int, H: int, W: int, Cc: int) -> torch.Tensor:
+    """[B*H*W, 4*Cc] (phase-major columns) -> NHWC [B, 2H, 2W, Cc] (as [B*2H*2W, Cc]): the second half of the phase-decomposed upsample convolution."""
+    assert x.dtype == BF16 and out.dtype == BF16 and x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel() == B * H * W * 4 * Cc
+    _chk(_lib.lib().pcdm_pixel_shuffle2(_ptr(x), _ptr(out), B, H, W, Cc, _stream(x)), "pcdm_pixel_shuffle2")
+    return out
 
 
 def pack_geglu(w: torch.Tensor, bias: torch.Tensor, device) -> PackedWeight:
@@ -258,7 +294,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
          ln: Optional[tuple] = None, ln_buf: Optional[torch.Tensor] = None, pw_ln: Optional[PackedWeight] = None,
          defer_reduce: Optional[bool] = None, dup_rows: int = 0, rowvec_step: Optional[torch.Tensor] = None,
          rowvec_step_stride: int = 0, row_stats: Optional[torch.Tensor] = None, rowvec_step_count: int = 0,
-         step_error: Optional[torch.Tensor] = None) -> Union[torch.Tensor, "DeferredGemm"]:
+         step_error: Optional[torch.Tensor] = None, tap_lut: int = 0, tap_group_n: int = 0) -> Union[torch.Tensor, "DeferredGemm"]:
     """out = epilogue(A @ W^T).  ``a`` [M, K1] (linear; optional ``a2`` [M, K2] = channel concat) or
     NHWC [B, Hi, Wi, cin] with ``conv=dict(B,Hi,Wi,Ho,Wo,stride,upsample)``.  A convolution whose packed weight has EXTRA K behind the nine
     taps (``pack_conv3x3_shortcut``: K = 9 cin + cx) contracts on over a 1x1 convolution of ``a2`` [M, c1] (and ``a3`` [M, cx - c1]) at the
@@ -297,7 +333,10 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         p.no_pad_lo = conv.get("no_pad_lo", 0)
         assert a.numel() == p.B * p.Hi * p.Wi * pw.cin, (a.shape, pw.cin)
         M = p.B * p.Ho * p.Wo
-        if a2 is not None:   # extra K: the 1x1 sources behind the taps
+        if tap_group_n:      # a subset of the nine taps per output-channel group (pack_upsample_phases; pcdm_gemm_params.tap_lut)
+            assert a2 is None and a3 is None and pw.K % pw.cin == 0 and pw.K // pw.cin <= 4, (pw.K, pw.cin)
+            p.tap_lut, p.tap_group_n = int(tap_lut), int(tap_group_n)
+        elif a2 is not None:   # extra K: the 1x1 sources behind the taps
             assert a2.dtype == BF16 and a2.dim() == 2 and a2.shape[0] == M and a2.stride(-1) == 1
             p.a2, p.lda2, p.c1 = _ptr(a2), a2.stride(0), a2.shape[1]
             cx = a2.shape[1]
@@ -355,7 +394,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
     split = 1
     key = None
     if tile == 0 and AUTOTUNE:
-        key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0), p.upsample, epilogue,
+        key = (M, pw.Npad, pw.K, p.conv, p.stride + (10 if p.no_pad_lo else 0) + (20 if tap_group_n else 0), p.upsample, epilogue,
                a2 is not None, residual is not None) + ((True,) if zero_rows else ((2,) if dup_rows else ()))   # (w_ld does not change the best tile)
         tile, split = _TUNED.get(key, (0, 1))
         if tile in ROWGEMM_TILES and (rowvec is not None or act != ACT_NONE or (residual is not None and res_mod < M)):
@@ -395,7 +434,7 @@ def gemm(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, a2: Optional[t
         # algorithmic FLOPs stay the un-hoisted 2*M*N*K also when zero_rows skips part of the contraction; the sixth
         # field is what the launch executes
         LAUNCH_LOG.append(("gemm_kernel", 2.0 * M * pw.alg_nk, e0, e1, (M, pw.N, pw.K, bool(conv), tile, split),
-                           2.0 * (M - zero_rows) * pw.alg_nk))
+                           2.0 * (M - zero_rows) * (pw.exec_nk or pw.alg_nk)))
         if LAUNCH_KEYS is not None and key is not None:
             LAUNCH_KEYS.append((len(LAUNCH_LOG) - 1, key))
         return out if deferred is None else deferred

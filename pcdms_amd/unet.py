@@ -44,6 +44,12 @@ FUSE_FF_OUT = os.environ.get("PCDM_FUSE_FF_OUT", "1") != "0"
 # conv2's nine taps (ops.pack_conv3x3_shortcut; pcdm_gemm_params.a3, ABI 5): the 14 shortcut launches of a step and the read-back of their
 # outputs as conv2's residual disappear.  PCDM_FUSE_SHORTCUT=0: the two launches (A/B switch, tools/README.md).
 FUSE_SHORTCUT = os.environ.get("PCDM_FUSE_SHORTCUT", "1") != "0"
+# Upsample2D: conv3x3(nearest-upsample x2 (x)) as its PHASE DECOMPOSITION (round 6).  Output pixel (2y + a, 2x + b) of the convolution on the
+# upsampled tensor reads only the low-res pixels {y - 1 + a, y + a} x {x - 1 + b, x + b}: four 2x2 convolutions of x with summed taps -- one
+# 3x3 launch on the LOW-RES tensor with N = 4 C (ops.pack_upsample_phases: each output-channel group = phase contracts over its four taps
+# only, pcdm_gemm_params.tap_lut) and a pixel shuffle: 4/9 of the FLOPs of the three most expensive convolutions of the step.  Used when the
+# target size is exactly (2 H, 2 W) (the reference's output_size path for odd skip sizes keeps the gather form).  PCDM_PHASE_UPSAMPLE=0: off.
+PHASE_UPSAMPLE = os.environ.get("PCDM_PHASE_UPSAMPLE", "1") != "0"
 
 _DEFAULT_CONFIG: Dict[str, Any] = dict(
     sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
@@ -393,6 +399,9 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
         for i in range(len(self._boc) - 1):
             w[f"down_blocks.{i}.downsamplers.0.conv."] = conv(f"down_blocks.{i}.downsamplers.0.conv.")
             w[f"up_blocks.{i}.upsamplers.0.conv."] = conv(f"up_blocks.{i}.upsamplers.0.conv.")
+            if PHASE_UPSAMPLE:
+                w[f"up_blocks.{i}.upsamplers.0.conv4."] = ops.pack_upsample_phases(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"],
+                                                                                   sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], dev)
         w["norm_out"] = (f32("conv_norm_out.weight"), f32("conv_norm_out.bias"))
         w["conv_out"] = conv("conv_out.")
         self._w = w
@@ -781,6 +790,13 @@ class Stage2_InapintUNet2DConditionModel(ModuleSurface):
                         taps[f"up{i}.{j}"] = x.clone()
             if i != nlev - 1:
                 ho, wo = skips[-1][1], skips[-1][2]      # = (2 hh, 2 ww) unless a down conv rounded an odd size up
+                w4 = W.get(f"up_blocks.{i}.upsamplers.0.conv4.")
+                if w4 is not None and (ho, wo) == (2 * hh, 2 * ww):   # the phase decomposition (PHASE_UPSAMPLE above): 4/9 of the FLOPs + a shuffle
+                    ph = ops.gemm(x.view(B, hh, ww, rev[i]), w4, self._buf("usp", (B * hh * ww, 4 * rev[i])),
+                                  conv=dict(B=B, Hi=hh, Wi=ww, Ho=hh, Wo=ww), tap_lut=ops.UPSAMPLE_TAP_LUT, tap_group_n=rev[i])
+                    x = ops.pixel_shuffle2(ph, self._buf("us", (B * ho * wo, rev[i])), B, hh, ww, rev[i])
+                    hh, ww = ho, wo
+                    continue
                 x = ops.gemm(x.view(B, hh, ww, rev[i]), W[f"up_blocks.{i}.upsamplers.0.conv."],
                              self._buf("us", (B * ho * wo, rev[i])),
                              conv=dict(B=B, Hi=hh, Wi=ww, Ho=ho, Wo=wo, upsample=1), defer_reduce=True)    # -> the next block's norm1

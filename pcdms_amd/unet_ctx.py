@@ -104,6 +104,8 @@ class UNetContext:
         for i in range(len(u._boc) - 1):
             self._set_w(f"down_blocks.{i}.downsamplers.0.conv", W[f"down_blocks.{i}.downsamplers.0.conv."])
             self._set_w(f"up_blocks.{i}.upsamplers.0.conv", W[f"up_blocks.{i}.upsamplers.0.conv."])
+            if f"up_blocks.{i}.upsamplers.0.conv4." in W:
+                self._set_w(f"up_blocks.{i}.upsamplers.0.conv4", W[f"up_blocks.{i}.upsamplers.0.conv4."])
         self._set_v("conv_norm_out", W["norm_out"])
 
     def sync_tiles(self) -> int:

@@ -491,6 +491,39 @@ def test_conv3x3_with_shortcut_k(backend, case):
         ops.gemm(hh, ops.pack_conv3x3(w.float(), bias, dev), torch.empty(M, C, dtype=BF16, device=dev), conv=cv, a2=a2)
 
 
+@pytest.mark.parametrize("case", ["default", "tiles"])
+def test_upsample_conv_phase_decomposition(backend, case):
+    """Upsample2D's ``conv3x3(nearest x2 (x))`` as one 3x3 launch on the LOW-RES tensor with N = 4 C -- every output-channel group (= output phase
+    (a, b)) contracts over its four taps only (pcdm_gemm_params.tap_lut; ops.pack_upsample_phases sums the taps that land on the same low-res
+    pixel) -- followed by ``pixel_shuffle2``: against F.conv2d on the F.interpolate'd tensor in fp32 and against the gather form of the same
+    library (tolerance: bf16 rounding of the summed weights).  Borders included (the zero padding of the upsampled tensor is the low-res
+    tensor's).  ``tiles``: every tile family a tuner may pick; a tile whose N width does not divide the group is refused (-1)."""
+    dev = backend.device
+    B, H, W, C = (2, 5, 3, 64) if backend.is_emu else (8, 32, 44, 640)
+    x = rnd(B, C, H, W, seed=260)
+    w = rnd(C, C, 3, 3, seed=261, scale=1 / math.sqrt(9 * C))
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(262))
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, C)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    pw4 = ops.pack_upsample_phases(w.float(), bias, dev)
+    assert pw4.N == 4 * C and pw4.K == 4 * C and pw4.cin == C
+    tiles = [0] if case == "default" else ([2, 8] if backend.is_emu else [22, 21, 11, 4, 1, 18, 10])
+    for tile in tiles:
+        ph = torch.empty(B * H * W, 4 * C, dtype=BF16, device=dev)
+        ops.gemm(xh, pw4, ph, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tap_lut=ops.UPSAMPLE_TAP_LUT, tap_group_n=C, tile=tile)
+        out = ops.pixel_shuffle2(ph, torch.empty(B * 4 * H * W, C, dtype=BF16, device=dev), B, H, W, C)
+        backend.sync()
+        close(out, ref)
+    # the gather form of the same convolution (upsample folded into the implicit GEMM: nine taps on the upsampled grid)
+    g = torch.empty(B * 4 * H * W, C, dtype=BF16, device=dev)
+    ops.gemm(xh, ops.pack_conv3x3(w.float(), bias, dev), g, conv=dict(B=B, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, upsample=1))
+    backend.sync()
+    assert ((out.float().cpu() - g.float().cpu()).norm() / g.float().cpu().norm()).item() < 6e-3
+    if not backend.is_emu:   # a 256-wide N tile does not divide a 640-channel group
+        with pytest.raises(RuntimeError):
+            ops.gemm(xh, pw4, ph, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tap_lut=ops.UPSAMPLE_TAP_LUT, tap_group_n=C, tile=17)
+
+
 def test_conv_in_padded_channels(backend):
     """conv_in: 9 input channels zero-padded to 64 (weights too) == the 9-channel conv."""
     dev = backend.device

@@ -193,6 +193,34 @@ def test_shortcut_fusion_matches_the_two_launches(backend, monkeypatch):
     assert ((outs[True] - outs[False]).norm() / outs[False].norm()).item() < 1e-2
 
 
+def test_phase_upsample_matches_the_gather_form(backend, monkeypatch):
+    """Upsample2D as its phase decomposition (pcdms_amd/unet.py PHASE_UPSAMPLE: one 3x3 launch on the low-res tensor with N = 4 C over four taps
+    per output-channel group + a pixel shuffle) against the gather form (nine taps on the upsampled grid): both inside the forward
+    tolerance against the fp32 oracle, and within bf16 rounding of the summed weights of each other."""
+    from pcdms_amd import unet as U
+    cfg = UNetConfig.tiny()
+    B, h, w, L = (2, 8, 8, 5) if backend.is_emu else (4, 16, 24, 10)
+    sd = synth_state_dict(cfg, seed=0, random_affine=True)
+    s, e, c, p = _inputs(cfg, B, h, w, L)
+    dev = backend.device
+    outs = {}
+    for phase in (True, False):
+        monkeypatch.setattr(U, "PHASE_UPSAMPLE", phase)
+        m = Stage2_InapintUNet2DConditionModel(**_kwargs(cfg))
+        m.load_state_dict(sd)
+        m.to(dev)
+        m._pack()
+        assert any(k.endswith("conv4.") for k in m._w if isinstance(k, str)) == phase
+        out = m(s.to(dev), torch.tensor(981, device=dev), e.to(dev), class_labels=c.to(dev), my_pose_cond=p.to(dev), return_dict=False)[0]
+        backend.sync()
+        outs[phase] = out.float().cpu()
+    ref = unet_forward(sd, cfg, s, torch.tensor(981), e, c, p)
+    rel_p, _ = _check(outs[True], ref)
+    rel_g, _ = _check(outs[False], ref)
+    assert rel_p <= rel_g * 1.25 + 1e-4, (rel_p, rel_g)
+    assert ((outs[True] - outs[False]).norm() / outs[False].norm()).item() < 1e-2
+
+
 @pytest.mark.gpu
 def test_unet_latent_not_divisible_by_8(gpu_backend):
     """Latent 20x11 (like the stage-3 latent 64x44 of a 352-wide image): the stride-2 convs round up (11 -> 6 -> 3 -> 2) and
