@@ -290,6 +290,7 @@ int pcdm_pixel_shuffle2(const void* in, void* out, int B, int H, int W, int C, p
  * sampling call pcdm_unet_prepare_conditioning (class embedding, pose feature, cross-attention K / V^T: step-invariant) and per denoise
  * step pcdm_unet_forward.  No allocation inside, every launch on the caller's stream, fixed scratch addresses (hipGraph-capturable).
  * Weight names (N = diffusers module path, e.g. "down_blocks.0.resnets.1." / "...attentions.0."):
+ *   optional "up_blocks.i.upsamplers.0.conv4" (the upsampler's convolution as four 2x2 phase kernels: pcdm_gemm_params.tap_lut; used when the target is 2H x 2W),
  *   conv_in, conv_out, N"conv1", N"conv2", N"conv_shortcut", optional N"conv2s" (conv2's packed rows with conv_shortcut's [N, Cx] appended along K,
  *   bias = the sum: when registered, conv2 + conv_shortcut of that resnet run as ONE launch through pcdm_gemm_params.a2 / a3), "down_blocks.i.downsamplers.0.conv", "up_blocks.i.upsamplers.0.conv"  (pcdm_pack conv3x3 / linear)
  *   N"proj_in", N"proj_out", N"qkv" (to_q|to_k|to_v rows), N"o1", N"q2", N"kv2" (to_k|to_v of attn2), N"o2", N"ff1" (GEGLU packing), N"ff2",

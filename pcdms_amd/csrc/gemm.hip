@@ -233,7 +233,8 @@ extern "C" int pcdm_gemm(const pcdm_gemm_params* p, pcdm_stream_t s) {
         if ((tile == 4 || tile == 7 || tile == 18) && p->Npad % 128) return -1;
         return pcdm_gemm_detail::launch_gemm_ext(3, tile, a, st);
     }
-    const bool n128 = p->Npad % 128 == 0;
+    // (a tap-subset convolution needs N tiles that lie inside one output-channel group: the heuristic's 128-wide tiles only when the group allows)
+    const bool n128 = p->Npad % 128 == 0 && (a.tap_group_n == 0 || a.tap_group_n % 128 == 0);
     const bool needs128 = tile == 1 || tile == 4 || tile == 7 || tile == 9 || tile == 11 || tile == 18;
     if (p->epilogue == PCDM_EPI_GEGLU && tile != 0 && !needs128 && tile < 13) return -1;  // GEGLU pairs need a 64-wide wave tile (19+: launch_gemm checks)
     if (tile == 0) {

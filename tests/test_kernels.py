@@ -522,6 +522,23 @@ def test_upsample_conv_phase_decomposition(backend, case):
     if not backend.is_emu:   # a 256-wide N tile does not divide a 640-channel group
         with pytest.raises(RuntimeError):
             ops.gemm(xh, pw4, ph, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tap_lut=ops.UPSAMPLE_TAP_LUT, tap_group_n=C, tile=17)
+        # the library's own heuristic (tile 0, no tuner: a host without Python) must pick a tile that fits the group: 64-channel groups at a
+        # size where it would otherwise take a 128-wide tile
+        Cn = 64
+        xn = rnd(B, Cn, H, W, seed=263)
+        wn = rnd(Cn, Cn, 3, 3, seed=264, scale=1 / math.sqrt(9 * Cn))
+        pwn = ops.pack_upsample_phases(wn.float(), None, dev)
+        phn = torch.empty(B * H * W, 4 * Cn, dtype=BF16, device=dev)
+        auto = ops.AUTOTUNE
+        ops.AUTOTUNE = False
+        try:
+            ops.gemm(xn.permute(0, 2, 3, 1).contiguous().to(dev), pwn, phn, conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W), tap_lut=ops.UPSAMPLE_TAP_LUT,
+                     tap_group_n=Cn)
+        finally:
+            ops.AUTOTUNE = auto
+        outn = ops.pixel_shuffle2(phn, torch.empty(B * 4 * H * W, Cn, dtype=BF16, device=dev), B, H, W, Cn)
+        backend.sync()
+        close(outn, F.conv2d(F.interpolate(xn.float(), scale_factor=2.0, mode="nearest"), wn.float(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, Cn))
 
 
 def test_conv_in_padded_channels(backend):
