@@ -216,7 +216,11 @@ class AutoencoderKL(ModuleSurface):
                 w[f"d.u{i}.r{j}"] = res(f"decoder.up_blocks.{i}.resnets.{j}.")
             if i != len(boc) - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv."
-                w[f"d.u{i}.us"] = ops.pack_conv3x3(sd[p + "weight"], sd[p + "bias"], dev)
+                from .unet import PHASE_UPSAMPLE
+                if PHASE_UPSAMPLE:   # Upsample2D as its phase decomposition (pcdms_amd/unet.py PHASE_UPSAMPLE: 4/9 of the FLOPs; the decoder's sizes are always x2)
+                    w[f"d.u{i}.us4"] = ops.pack_upsample_phases(sd[p + "weight"], sd[p + "bias"], dev)
+                else:
+                    w[f"d.u{i}.us"] = ops.pack_conv3x3(sd[p + "weight"], sd[p + "bias"], dev)
         w["d.norm_out"] = (f32("decoder.conv_norm_out.weight"), f32("decoder.conv_norm_out.bias"))
         oc = self.config.out_channels
         wout = torch.zeros(4, *sd["decoder.conv_out.weight"].shape[1:])   # N must be a multiple of 4: pad 3 -> 4
@@ -323,9 +327,14 @@ class AutoencoderKL(ModuleSurface):
         for i in range(len(boc)):
             for j in range(L + 1):
                 h = self._resnet(W_[f"d.u{i}.r{j}"], h, B, H, W, "ra" if j % 2 == 0 else "rb")
-            if i != len(boc) - 1:   # Upsample2D: nearest x2 folded into the conv's gather
-                h = ops.gemm(h, W_[f"d.u{i}.us"], self._buf("us", (B * 4 * H * W, rev[i])),
-                             conv=dict(B=B, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, upsample=1))
+            if i != len(boc) - 1:
+                if f"d.u{i}.us4" in W_:   # Upsample2D as four 2x2 phase kernels on the low-res tensor (one launch, N = 4 C) + a pixel shuffle
+                    ph = ops.gemm(h, W_[f"d.u{i}.us4"], self._buf("usp", (B * H * W, 4 * rev[i])), conv=dict(B=B, Hi=H, Wi=W, Ho=H, Wo=W),
+                                  tap_lut=ops.UPSAMPLE_TAP_LUT, tap_group_n=rev[i])
+                    h = ops.pixel_shuffle2(ph, self._buf("us", (B * 4 * H * W, rev[i])), B, H, W, rev[i])
+                else:               # nearest x2 folded into the conv's gather
+                    h = ops.gemm(h, W_[f"d.u{i}.us"], self._buf("us", (B * 4 * H * W, rev[i])),
+                                 conv=dict(B=B, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, upsample=1))
                 H, W = 2 * H, 2 * W
         n = self._gn(h, B, H * W, W_["d.norm_out"], True, "gn")
         img4 = self._buf("img4", (B, 4, H, W), torch.float32)      # 3 channels + 1 padding channel
