@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--out", default="gpurun_out/r6_tune_in_step.json")
     ap.add_argument("--batch", type=int, default=4, help="generated images per call (UNet batch = 2 x this): 4 = configs[1], 8 = the per-GPU share of configs[2]")
     ap.add_argument("--skip-plain", action="store_true", help="only the LayerNorm -> Linear pairs")
+    ap.add_argument("--add-only", action="store_true", help="tune nothing: run the step (the online autotuner picks tiles for unseen shapes at first use) and, with "
+                                                            "--write, add the keys the table does not know yet -- no existing entry can move")
     ap.add_argument("--width", type=int, default=352, help="single image width (the stage-2 canvas is twice this): 352 = the metric's, 512 = the driver's default")
     ap.add_argument("--stage3", action="store_true", help="the stage-3 refine UNet (in_channels 8, no class / pose embedding) on one image of --width: "
                                                           "N = --batch samples, as stage3_batchtest_refined_model.py runs it")
@@ -135,7 +137,7 @@ def main():
 
     report, changed = [], {}
     t_start = time.time()
-    for key in ([] if args.skip_plain else sorted(plain, key=lambda k: -sum(ms0[i] for i in by_key[k]))):
+    for key in ([] if (args.skip_plain or args.add_only) else sorted(plain, key=lambda k: -sum(ms0[i] for i in by_key[k]))):
         M, Npad, K, conv, stride, ups, epi = key[:7]
         cur = ops._TUNED.get(key)
         if cur is None:
@@ -208,7 +210,7 @@ def main():
             t += sum(log[i][2].elapsed_time(log[i][3]) for i, k in keys if k in producer_keys)
             vals.append(t)
         return min(vals), lat
-    for key in ([] if args.only else ln_keys):
+    for key in ([] if (args.only or args.add_only) else ln_keys):
         _, M, Npad, K, epi = key
         cur = ops._TUNED.get(key)
         if cur is None:
